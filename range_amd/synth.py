@@ -1,0 +1,145 @@
+"""Seeded synthetic checkpoints, banks and queries.
+
+The real SatCLIP checkpoint and ``range_db_*.npz`` files are not available offline
+(SURVEY.md section 0, fact 5), so every test, golden vector and benchmark uses data made here.
+The *formats* follow the reference exactly so that the same loader path is exercised:
+
+* checkpoint: Lightning-style dict ``{'hyper_parameters': {...}, 'state_dict': {...}}`` with the
+  location-encoder tensors under ``model.location.nnet.layers.{i}.{weight,bias}`` and
+  ``model.location.nnet.last_layer.{weight,bias}`` (reference: satclip/load.py:3-18,
+  satclip/location_encoder.py:73-96, satclip/model_old.py:326-330).
+* bank: ``np.savez(locs=(N,2) f64 (lon,lat) deg, image_embeddings=(N,1024),
+  satclip_embeddings=(N,256))`` (reference: range/generate_db.py:209-214).
+
+Shapes H (capacity) and N are assumptions for the real files.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+EMBED_DIM = 256
+VALUE_DIM = 1024
+
+# Named synthetic banks (row counts are assumptions).
+BANK_ROWS = {"range_db_med": 50_000, "range_db_large": 100_000}
+
+
+def make_encoder_weights(L: int = 40, hidden: int = 512, embed_dim: int = EMBED_DIM,
+                         num_hidden_layers: int = 2, seed: int = 1234) -> Dict[str, np.ndarray]:
+    """SIREN-initialised float64 weights, torch ``(out, in)`` layout.
+
+    Init ranges follow satclip/location_encoder.py:137-144 with w0=1: first layer
+    U(-1/dim_in, 1/dim_in), later layers U(-sqrt(6/dim_in), sqrt(6/dim_in)).
+    Returns ``{'layers.0.weight': ..., 'layers.0.bias': ..., ..., 'last_layer.weight': ...}``.
+    """
+    rng = np.random.default_rng(seed)
+    F = L * L
+    out: Dict[str, np.ndarray] = {}
+    dim_in = F
+    for i in range(num_hidden_layers):
+        w_std = (1.0 / dim_in) if i == 0 else math.sqrt(6.0 / dim_in)
+        out[f"layers.{i}.weight"] = rng.uniform(-w_std, w_std, size=(hidden, dim_in))
+        out[f"layers.{i}.bias"] = rng.uniform(-w_std, w_std, size=(hidden,))
+        dim_in = hidden
+    w_std = math.sqrt(6.0 / dim_in)
+    out["last_layer.weight"] = rng.uniform(-w_std, w_std, size=(embed_dim, dim_in))
+    out["last_layer.bias"] = rng.uniform(-w_std, w_std, size=(embed_dim,))
+    return out
+
+
+def default_hparams(L: int = 40, hidden: int = 512, embed_dim: int = EMBED_DIM,
+                    num_hidden_layers: int = 2,
+                    harmonics_calculation: str = "analytic") -> Dict[str, object]:
+    """Hyper-parameters in the shape the reference's checkpoint carries
+    (satclip/main_old.py:15-37; the three popped keys of satclip/load.py:5-7 included)."""
+    return {
+        "embed_dim": embed_dim,
+        "image_resolution": 32,
+        "vision_layers": 1,
+        "vision_width": 64,
+        "vision_patch_size": 16,
+        "in_channels": 4,
+        "le_type": "sphericalharmonics",
+        "pe_type": "siren",
+        "frequency_num": 16,
+        "max_radius": 260,
+        "min_radius": 1,
+        "legendre_polys": L,
+        "harmonics_calculation": harmonics_calculation,
+        "sh_embedding_dims": 32,
+        "learning_rate": 1e-4,
+        "weight_decay": 0.01,
+        "num_hidden_layers": num_hidden_layers,
+        "capacity": hidden,
+        "eval_downstream": False,
+        "air_temp_data_path": "",
+        "election_data_path": "",
+    }
+
+
+def make_checkpoint(L: int = 40, hidden: int = 512, embed_dim: int = EMBED_DIM,
+                    num_hidden_layers: int = 2, seed: int = 1234,
+                    harmonics_calculation: str = "analytic") -> Dict[str, object]:
+    """A checkpoint dict holding only what the RANGE path reads (no vision tower)."""
+    import torch
+
+    w = make_encoder_weights(L, hidden, embed_dim, num_hidden_layers, seed)
+    sd = {}
+    for k, v in w.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        sd[f"model.location.nnet.{k}"] = t
+        sd[f"model.nnet.{k}"] = t  # the reference ckpt carries both aliases
+    return {"hyper_parameters": default_hparams(L, hidden, embed_dim, num_hidden_layers,
+                                                harmonics_calculation),
+            "state_dict": sd}
+
+
+def write_checkpoint(path: str, **kw) -> str:
+    import torch
+
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(make_checkpoint(**kw), path)
+    return path
+
+
+def make_bank(n_rows: int, seed: int = 2024, n_clusters: int = 32,
+              key_dim: int = EMBED_DIM, value_dim: int = VALUE_DIM
+              ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Synthetic bank arrays ``(locs f64 (N,2) lon/lat deg, image_embeddings f32 (N,1024),
+    satclip_embeddings f32 (N,256))``: locations uniform on the sphere, keys N(0,1) plus one of
+    ``n_clusters`` random centres x3 (so similarities are not all ~0), values N(0,1)."""
+    rng = np.random.default_rng(seed)
+    lon = rng.uniform(-180.0, 180.0, size=n_rows)
+    lat = np.degrees(np.arcsin(rng.uniform(-1.0, 1.0, size=n_rows)))
+    locs = np.stack([lon, lat], axis=1).astype(np.float64)
+    centres = rng.standard_normal((n_clusters, key_dim)).astype(np.float32)
+    which = rng.integers(0, n_clusters, size=n_rows)
+    keys = rng.standard_normal((n_rows, key_dim), dtype=np.float32) + 3.0 * centres[which]
+    values = rng.standard_normal((n_rows, value_dim), dtype=np.float32)
+    return locs, values, keys.astype(np.float32)
+
+
+def write_bank(path: str, n_rows: int, seed: int = 2024, **kw) -> str:
+    """Write the bank with the reference's schema (generate_db.py:212-214, uncompressed savez)."""
+    locs, values, keys = make_bank(n_rows, seed, **kw)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.savez(path, locs=locs, image_embeddings=values, satclip_embeddings=keys)
+    return path if path.endswith(".npz") else path + ".npz"
+
+
+def make_queries(n: int, seed: int = 7, lat_max: float = 45.0, lat_min: float | None = None
+                 ) -> np.ndarray:
+    """(n,2) float64 (lon, lat) degrees. Default: the gated parity band |lat|<=45
+    (SURVEY.md section 8(c)); pass lat_min/lat_max for the polar set."""
+    rng = np.random.default_rng(seed)
+    lon = rng.uniform(-180.0, 180.0, size=n)
+    if lat_min is None:
+        lat = rng.uniform(-lat_max, lat_max, size=n)
+    else:
+        mag = rng.uniform(lat_min, lat_max, size=n)
+        lat = mag * rng.choice([-1.0, 1.0], size=n)
+    return np.stack([lon, lat], axis=1).astype(np.float64)

@@ -1,0 +1,145 @@
+"""Pin the CPU oracle (oracle/range_oracle.py) against golden vectors produced by running the
+reference's own Python (tests/golden/make_golden.py).  CPU only."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import range_oracle as O
+from range_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ENC = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "enc_*.npz")))
+E2E = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "e2e_*.npz")))
+
+
+def test_manifest_lists_every_fixture():
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    assert sorted(man["cases"]) == sorted(ENC + E2E)
+    # error behaviour of the reference loader (range/load_model.py:31-34, range.py:113-114,199-200)
+    assert man["errors"] == {"no_pretrained_path": "ValueError", "no_db_path": "AssertionError",
+                             "bad_range_name": "ValueError", "unknown_model": "NotImplementedError"}
+
+
+@pytest.mark.parametrize("tag", ENC)
+def test_sh_and_encoder_vs_reference(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    q, L, mode = z["lonlat"], int(z["L"]), str(z["mode"])
+    Y = O.sh_features(q, L, mode)
+    rows = z["sh_rows"]
+    d = np.abs(Y[rows] - z["sh_features"]).max(axis=1)
+    lat = np.abs(q[rows, 1])
+    w = synth.make_encoder_weights(L, int(z["hidden"]), 256, int(z["num_hidden_layers"]),
+                                   int(z["seed"]))
+    e = O.siren_forward(Y, w)
+    de = np.abs(e - z["embedding"]).max(axis=1)
+    latq = np.abs(q[:, 1])
+    if mode == "closed-form" or L <= 16:
+        # the reference's recurrence (and its low-degree polynomials) are well conditioned
+        # everywhere: the restatement must agree to rounding at every latitude
+        tol = 5e-12 if mode == "closed-form" else 5e-9   # analytic L=16 is ~1e-10 at 75 deg
+        assert d.max() < tol
+        assert de.max() < tol
+    else:
+        # analytic L=40: the reference's expanded polynomials are ill-conditioned in float64
+        # away from the equator; gate on the |lat|<=45 band
+        assert d[lat <= 30].max() < 1e-7
+        assert d[lat <= 45].max() < 2e-4
+        assert de[latq <= 30].max() < 1e-8
+        assert de[latq <= 45].max() < 2e-5
+        # and the analytic convention itself is exact: compare against closed-form x factor
+        Yc = O.sh_features(q, L, "closed-form")
+        for l in range(L):
+            for m in range(-l, l + 1):
+                f = np.pi if m == 0 else (-1.0) ** m
+                np.testing.assert_allclose(Y[:, l * l + l + m], f * Yc[:, l * l + l + m],
+                                           rtol=1e-13, atol=1e-15)
+
+
+def test_sh_matches_scipy_orthonormal():
+    """Independent check of the recurrence against scipy's associated Legendre functions."""
+    from scipy.special import lpmv, gammaln
+    q = synth.make_queries(64, seed=3, lat_max=89.9)
+    L = 24
+    Y = O.sh_features(q, L, "closed-form")
+    phi, theta = O.sh_angles(q)
+    x = np.cos(theta)
+    for l in (0, 1, 2, 7, 15, 23):
+        for m in range(-l, l + 1):
+            am = abs(m)
+            N = np.sqrt((2 * l + 1) / (4 * np.pi) * np.exp(gammaln(l - am + 1) - gammaln(l + am + 1)))
+            P = lpmv(am, l, x)  # includes the Condon-Shortley phase, like the closed form
+            if m == 0:
+                ref = N * P
+            elif m > 0:
+                ref = np.sqrt(2) * N * np.cos(m * phi) * P
+            else:
+                ref = np.sqrt(2) * N * np.sin(am * phi) * P
+            np.testing.assert_allclose(Y[:, l * l + l + m], ref, rtol=1e-10, atol=1e-12)
+
+
+def _bank_and_weights(z):
+    locs, vals, keys = synth.make_bank(int(z["bank_rows"]), int(z["bank_seed"]))
+    bank = O.prep_bank(locs, vals, keys)
+    w = synth.make_encoder_weights(int(z["L"]), int(z["hidden"]), 256,
+                                   int(z["num_hidden_layers"]), int(z["weight_seed"]))
+    return bank, w
+
+
+@pytest.mark.parametrize("tag", E2E)
+def test_retrieval_bitwise_vs_reference(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    bank, w = _bank_and_weights(z)
+    q = z["lonlat"]
+    e_ref = z["range"][:, 1024:]
+    out = O.retrieve(e_ref, q, bank, "RANGE", None)
+    assert out.dtype == np.float64 and out.shape == (q.shape[0], 1280)
+    assert np.array_equal(out, z["range"])
+    for beta in (0.0, 0.25, 0.5, 0.75, 1.0):
+        assert np.array_equal(O.retrieve(e_ref, q, bank, "RANGE+", beta),
+                              z[f"rangeplus_beta{beta}"]), beta
+
+
+@pytest.mark.parametrize("tag", E2E)
+def test_full_forward_vs_reference(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    bank, w = _bank_and_weights(z)
+    q = z["lonlat"]
+    for name, beta, key in (("RANGE", None, "range"), ("RANGE+", 0.5, "rangeplus_beta0.5"),
+                            ("RANGE+", 0.0, "rangeplus_beta0.0")):
+        out = O.forward(q, w, int(z["L"]), bank, name, beta)
+        # |lat|<=45 queries: north_star tolerance 1e-4; measured ~5e-7
+        np.testing.assert_allclose(out, z[key], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", E2E)
+def test_topk_vs_reference(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    bank, _ = _bank_and_weights(z)
+    s, _ = O.logits64(z["range"][:, 1024:], z["lonlat"], bank)
+    tv, ti = O.topk64(s, 16)
+    assert np.array_equal(ti, z["sem_topk_idx"])
+    np.testing.assert_allclose(tv, z["sem_topk_val"], rtol=0, atol=1e-6)
+
+
+def test_retrieve64_close_to_f32_path():
+    locs, vals, keys = synth.make_bank(777, 5)
+    bank = O.prep_bank(locs, vals, keys)
+    w = synth.make_encoder_weights(10, 64, 256, 2, 5)
+    q = synth.make_queries(19, seed=1)
+    e = O.encode(q, w, 10)
+    for name, beta in (("RANGE", None), ("RANGE+", 0.3)):
+        a = O.retrieve(e, q, bank, name, beta)[:, :1024]
+        b = O.retrieve64(e, q, bank, name, beta)
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-6)
+
+
+def test_bank_prep_dtypes_and_norms():
+    locs, vals, keys = synth.make_bank(100, 1)
+    bank = O.prep_bank(locs, vals, keys)
+    assert bank.keys.dtype == bank.values.dtype == bank.xyz.dtype == np.float32
+    np.testing.assert_allclose(np.linalg.norm(bank.keys, axis=1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(bank.xyz, axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(bank.values, vals)
