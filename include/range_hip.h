@@ -1,0 +1,146 @@
+/*
+ * range_hip.h - C ABI of librange_hip.so: the MI355X (gfx950) engine behind
+ * range_amd.load_model(...)(locs), the drop-in for the RANGE / RANGE+ forward path of mvrl/RANGE.
+ *
+ * The reference is pure Python / PyTorch and has NO plugin, operator or FFI layer for this path
+ * (SURVEY.md section 8(b)); the "interface each entry point replaces" is therefore a span of the
+ * reference's Python, cited per function as file:line relative to the reference root.
+ * The Python host (range_amd/_native.py, ctypes) is the only intended caller, but nothing here
+ * depends on Python or torch: plain pointers, sizes and a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - every function returns RANGE_OK (0) or a negative error code; range_last_error() gives the
+ *     message of the last failure on the calling thread.  Nothing throws across the ABI.
+ *   - "dev" pointers are device memory owned by the caller (e.g. torch tensors' data_ptr());
+ *     "host" pointers are ordinary host memory, only read during the call.
+ *   - a ctx is bound to one GPU, is not thread-safe, owns its bank copy and workspace
+ *     (hipMalloc), and may be used from any stream; calls are asynchronous on `stream` except
+ *     where stated.  Several ctxs (one per GPU / per process) may coexist.
+ *   - all kernels are hand-written HIP for gfx950; there is no CPU fallback.
+ */
+#ifndef RANGE_HIP_H
+#define RANGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RANGE_ABI_VERSION 1
+
+#define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
+#define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
+#define RANGE_OUT_DIM 1280  /* location_feature_dim,     range/range.py:86     */
+
+enum {
+    RANGE_OK = 0,
+    RANGE_ERR_INVALID = -1, /* bad argument / unsupported shape */
+    RANGE_ERR_HIP = -2,     /* a HIP runtime call failed */
+    RANGE_ERR_STATE = -3,   /* encoder or bank not set */
+    RANGE_ERR_NOMEM = -4
+};
+
+enum { RANGE_SH_ANALYTIC = 0, RANGE_SH_CLOSED_FORM = 1 };
+enum { RANGE_MODEL_RANGE = 0, RANGE_MODEL_RANGE_PLUS = 1 };
+
+typedef struct range_ctx range_ctx;
+typedef void* range_stream_t; /* hipStream_t */
+
+/* Hyper-parameters of the SatCLIP location encoder, as carried by the checkpoint's
+ * hyper_parameters (satclip/main_old.py:15-37; satclip/model_old.py:326-330). */
+typedef struct range_encoder_desc {
+    int32_t legendre_polys;    /* L; SH feature count is L*L (spherical_harmonics.py:19-20) */
+    int32_t hidden;            /* capacity H; multiple of 64, <= 512 */
+    int32_t num_hidden_layers; /* SirenNet num_layers (>= 1) */
+    int32_t embed_dim;         /* must be RANGE_KEY_DIM */
+    int32_t sh_mode;           /* RANGE_SH_ANALYTIC | RANGE_SH_CLOSED_FORM (spherical_harmonics.py:22-25) */
+} range_encoder_desc;
+
+int range_abi_version(void);
+const char* range_last_error(void);
+
+/* Create / destroy an engine context on GPU `device`. */
+int range_create(int device, range_ctx** out);
+void range_destroy(range_ctx* ctx);
+
+/* Replaces get_satclip(...).double() + the module tree it builds
+ * (satclip/load.py:3-18, satclip/location_encoder.py:73-112, 267-275; range/range.py:82-84).
+ * weights[i] / biases[i], i = 0..num_hidden_layers: float64 HOST arrays in torch (out,in)
+ * row-major layout: layers.{i}.weight (H x in), layers.{i}.bias (H), last entry = last_layer
+ * (embed_dim x H).  The library re-packs them into MFMA fragment order on the device.
+ * Synchronous. */
+int range_set_encoder(range_ctx* ctx, const range_encoder_desc* desc,
+                      const double* const* weights, const double* const* biases);
+
+/* Replaces the bank upload of range/range.py:98-100 (and the per-forward re-upload of the values
+ * at :217/:236).  Inputs are HOST arrays already prepared exactly as range/range.py:78-95 does:
+ * keys (n_rows x 256) float32 rows L2-normalised in float32; values (n_rows x 1024) float32;
+ * xyz (n_rows x 3) float32 unit vectors.  For a row-sharded bank pass this rank's rows and the
+ * global index of its first row (used only to report top-k indices).  Synchronous. */
+int range_set_bank(range_ctx* ctx, const float* keys, const float* values, const float* xyz,
+                   int64_t n_rows, int64_t row_offset);
+int64_t range_bank_rows(const range_ctx* ctx);
+
+/* Kernel A.  Replaces self.loc_model(coords) and the normalisation of range/range.py:210-212
+ * (spherical_harmonics.py:27-42 + location_encoder.py:98-112, fused, float64) and the query half
+ * of range/range.py:225-229 (degrees -> unit xyz).
+ *   lonlat_dev : (B,2) float64, (lon,lat) degrees
+ *   ehat64_dev : (B,256) float64   normalised embedding (output columns 1024:1280)
+ *   ehat32_dev : (B,256) float32   the .float() operand of range.py:213
+ *   xq32_dev   : (B,4)   float32   (x,y,z,0), the .float() operand of range.py:231 */
+int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* ehat64_dev,
+                 float* ehat32_dev, float* xq32_dev, range_stream_t stream);
+
+/* Kernel B, pass 1.  Streaming log-sum-exp statistics of the temperature-scaled logits of
+ * range/range.py:213-215 (semantic) and :231-234 (geographic) over THIS ctx's bank rows.
+ *   tau_sem, tau_geo : temperatures (range.py:103, 108-109); tau_geo <= 0 disables the geo head
+ *   stats_dev : (B,4) float32 = {m_sem, l_sem, m_geo, l_geo}, m = max of tau*log2(e)*logit,
+ *               l = sum 2^(t - m) over the rows.  Opaque to callers except through
+ *               range_merge_stats.
+ *   topk : 0, or k in [1,16]: also emit the k largest semantic similarities of each query
+ *          (the "brute-force top-k" side channel), descending, ties -> lower row index:
+ *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local) */
+int range_scan_stats(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
+                     float tau_sem, float tau_geo, float* stats_dev, int topk,
+                     float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
+
+/* Exact merge of per-shard statistics (row-sharded bank): parts_dev is (n_parts,B,4) as written
+ * by range_scan_stats on each shard (e.g. after an all-gather); out_dev is (B,4). */
+int range_merge_stats(range_ctx* ctx, const float* parts_dev, int32_t n_parts, int64_t B,
+                      float* out_dev, range_stream_t stream);
+
+/* Merge per-shard top-k candidate lists: (n_parts,B,k) values / global indices -> (B,k). */
+int range_merge_topk(range_ctx* ctx, const float* val_parts_dev, const int64_t* idx_parts_dev,
+                     int32_t n_parts, int64_t B, int32_t k, float* val_out_dev,
+                     int64_t* idx_out_dev, range_stream_t stream);
+
+/* Kernel B, pass 2.  Replaces range/range.py:213-217, 231-238: with the GLOBAL statistics of
+ * pass 1 it recomputes the logits tile by tile, forms w = beta*p_sem + (1-beta)*p_geo and
+ * accumulates w @ values over THIS ctx's rows (float32 MFMA, exact f32 products).
+ *   beta : range.py:238 blend; with tau_geo <= 0 (plain RANGE, range.py:222) pass beta = 1
+ *   partial_dev : (B,1024) float32.  Partials of different shards simply add. */
+int range_attend(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
+                 float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
+                 float* partial_dev, range_stream_t stream);
+
+/* Replaces the pack of range/range.py:222 / :240: out (B,1280) float64 =
+ * [ sum over parts of partials (n_parts,B,1024) f32 widened | ehat64 (B,256) ]. */
+int range_finalize(range_ctx* ctx, const float* partials_dev, int32_t n_parts,
+                   const double* ehat64_dev, int64_t B, double* out_dev, range_stream_t stream);
+
+/* Whole path on one GPU (bank not sharded): encode -> stats -> attend -> finalize.
+ * Replaces LocationEncoder.forward for 'RANGE' / 'RANGE+' (range/range.py:206-240) up to the
+ * final device->host copy, which stays in the Python shim.
+ *   model : RANGE_MODEL_RANGE (tau 15) | RANGE_MODEL_RANGE_PLUS (tau 12 / 40, beta blend)
+ *   out_dev : (B,1280) float64 */
+int range_forward(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t model, float beta,
+                  double* out_dev, range_stream_t stream);
+
+/* Introspection for the bench harness: names/launch geometry of the last attend launch. */
+int range_last_attend_geometry(const range_ctx* ctx, int32_t* n_query_tiles, int32_t* n_splits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANGE_HIP_H */

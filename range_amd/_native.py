@@ -1,0 +1,254 @@
+"""ctypes binding of librange_hip.so (C ABI: include/range_hip.h).
+
+There is NO CPU fallback: if the library is missing or no gfx950 GPU is visible the product path
+raises.  Only plain pointers / sizes cross the boundary; torch is used for device memory and
+streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+LIB_NAME = "librange_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+KEY_DIM, VAL_DIM, OUT_DIM = 256, 1024, 1280
+SH_ANALYTIC, SH_CLOSED_FORM = 0, 1
+MODEL_RANGE, MODEL_RANGE_PLUS = 0, 1
+MAX_TOPK = 16
+
+# every symbol include/range_hip.h declares
+SYMBOLS = (
+    "range_abi_version", "range_last_error", "range_create", "range_destroy", "range_set_encoder",
+    "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
+    "range_merge_topk", "range_attend", "range_finalize", "range_forward",
+    "range_last_attend_geometry",
+)
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("legendre_polys", C.c_int32), ("hidden", C.c_int32),
+                ("num_hidden_layers", C.c_int32), ("embed_dim", C.c_int32),
+                ("sh_mode", C.c_int32)]
+
+
+class RangeNativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load librange_hip.so (built in-tree by ./build.sh or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RangeNativeError(
+            f"{LIB_PATH} not found. Build it with ./build.sh (hipcc --offload-arch=gfx950). "
+            "range_amd has no CPU fallback: the HIP extension is the product.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.range_abi_version.restype = C.c_int
+    lib.range_last_error.restype = C.c_char_p
+    lib.range_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.range_destroy.argtypes = [vp]
+    lib.range_destroy.restype = None
+    lib.range_set_encoder.argtypes = [vp, C.POINTER(EncoderDesc), C.POINTER(vp), C.POINTER(vp)]
+    lib.range_set_bank.argtypes = [vp, vp, vp, vp, i64, i64]
+    lib.range_bank_rows.argtypes = [vp]
+    lib.range_bank_rows.restype = i64
+    lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    lib.range_scan_stats.argtypes = [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp, vp, vp]
+    lib.range_merge_stats.argtypes = [vp, vp, i32, i64, vp, vp]
+    lib.range_merge_topk.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp]
+    lib.range_attend.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, vp]
+    lib.range_finalize.argtypes = [vp, vp, i32, vp, i64, vp, vp]
+    lib.range_forward.argtypes = [vp, vp, i64, i32, f32, vp, vp]
+    lib.range_last_attend_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    for name in SYMBOLS:
+        getattr(lib, name)
+    if lib.range_abi_version() != 1:
+        raise RangeNativeError("librange_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        raise RangeNativeError(f"librange_hip error {rc}: {lib.range_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipEngine:
+    """One engine context on one GPU.  All tensor arguments are CUDA(HIP) tensors on that GPU;
+    work is enqueued on torch's current stream for the device."""
+
+    def __init__(self, device: torch.device | int | str = 0):
+        self.lib = load_library()
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.type != "cuda":
+            raise RangeNativeError(f"range_amd needs a GPU device, got {dev}")
+        if not torch.cuda.is_available():
+            raise RangeNativeError("no GPU visible: range_amd runs only on MI355X (gfx950); "
+                                   "there is no CPU fallback")
+        self.device = torch.device("cuda", dev.index if dev.index is not None
+                                   else torch.cuda.current_device())
+        h = C.c_void_p()
+        _check(self.lib, self.lib.range_create(self.device.index, C.byref(h)))
+        self._h = h
+        self.n_rows = 0
+        self.row_offset = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.range_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ---------------------------------------------------------------------------------
+    def set_encoder(self, L: int, hidden: int, num_hidden_layers: int, embed_dim: int,
+                    sh_mode: int, weights: Sequence[np.ndarray],
+                    biases: Sequence[np.ndarray]) -> None:
+        n = num_hidden_layers + 1
+        if len(weights) != n or len(biases) != n:
+            raise ValueError("need num_hidden_layers+1 weight and bias arrays")
+        ws = [np.ascontiguousarray(w, dtype=np.float64) for w in weights]
+        bs = [np.ascontiguousarray(b, dtype=np.float64) for b in biases]
+        dims_in = [L * L] + [hidden] * num_hidden_layers
+        dims_out = [hidden] * num_hidden_layers + [embed_dim]
+        for i in range(n):
+            if ws[i].shape != (dims_out[i], dims_in[i]) or bs[i].shape != (dims_out[i],):
+                raise ValueError(f"layer {i}: weight {ws[i].shape} / bias {bs[i].shape} do not "
+                                 f"match ({dims_out[i]},{dims_in[i]})")
+        desc = EncoderDesc(L, hidden, num_hidden_layers, embed_dim, sh_mode)
+        wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        _check(self.lib, self.lib.range_set_encoder(self._h, C.byref(desc), wp, bp))
+
+    def set_bank(self, keys: np.ndarray, values: np.ndarray, xyz: np.ndarray,
+                 row_offset: int = 0) -> None:
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = keys.shape[0]
+        if keys.shape != (n, KEY_DIM) or values.shape != (n, VAL_DIM) or xyz.shape != (n, 3):
+            raise ValueError(f"bank shapes {keys.shape} {values.shape} {xyz.shape}")
+        _check(self.lib, self.lib.range_set_bank(self._h, keys.ctypes.data, values.ctypes.data,
+                                                 xyz.ctypes.data, n, row_offset))
+        self.n_rows = n
+        self.row_offset = row_offset
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _t(self, t: torch.Tensor, dtype, shape_tail) -> torch.Tensor:
+        if t.device != self.device:
+            raise ValueError(f"tensor on {t.device}, engine on {self.device}")
+        if t.dtype != dtype or tuple(t.shape[1:]) != tuple(shape_tail) or not t.is_contiguous():
+            raise ValueError(f"expected contiguous {dtype} (*,{shape_tail}), got {t.dtype} {tuple(t.shape)}")
+        return t
+
+    def _empty(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # -- kernels -------------------------------------------------------------------------------
+    def encode(self, lonlat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        self._t(lonlat, torch.float64, (2,))
+        B = lonlat.shape[0]
+        e64 = self._empty((B, KEY_DIM), torch.float64)
+        e32 = self._empty((B, KEY_DIM), torch.float32)
+        xq = self._empty((B, 4), torch.float32)
+        _check(self.lib, self.lib.range_encode(self._h, lonlat.data_ptr(), B, e64.data_ptr(),
+                                               e32.data_ptr(), xq.data_ptr(), self._stream()))
+        return e64, e32, xq
+
+    def scan_stats(self, e32: torch.Tensor, xq: torch.Tensor, tau_sem: float, tau_geo: float,
+                   topk: int = 0):
+        self._t(e32, torch.float32, (KEY_DIM,))
+        self._t(xq, torch.float32, (4,))
+        B = e32.shape[0]
+        stats = self._empty((B, 4), torch.float32)
+        tv = ti = None
+        if topk:
+            tv = self._empty((B, topk), torch.float32)
+            ti = self._empty((B, topk), torch.int64)
+        _check(self.lib, self.lib.range_scan_stats(self._h, e32.data_ptr(), xq.data_ptr(), B,
+                                                   tau_sem, tau_geo, stats.data_ptr(), topk,
+                                                   _ptr(tv), _ptr(ti), self._stream()))
+        return (stats, tv, ti) if topk else stats
+
+    def merge_stats(self, parts: torch.Tensor) -> torch.Tensor:
+        if parts.dim() != 3 or parts.shape[2] != 4:
+            raise ValueError("parts must be (n_parts,B,4)")
+        self._t(parts, torch.float32, parts.shape[1:])
+        P, B = parts.shape[0], parts.shape[1]
+        out = self._empty((B, 4), torch.float32)
+        _check(self.lib, self.lib.range_merge_stats(self._h, parts.data_ptr(), P, B,
+                                                    out.data_ptr(), self._stream()))
+        return out
+
+    def merge_topk(self, val_parts: torch.Tensor, idx_parts: torch.Tensor):
+        P, B, k = val_parts.shape
+        self._t(val_parts, torch.float32, (B, k))
+        self._t(idx_parts, torch.int64, (B, k))
+        ov = self._empty((B, k), torch.float32)
+        oi = self._empty((B, k), torch.int64)
+        _check(self.lib, self.lib.range_merge_topk(self._h, val_parts.data_ptr(),
+                                                   idx_parts.data_ptr(), P, B, k, ov.data_ptr(),
+                                                   oi.data_ptr(), self._stream()))
+        return ov, oi
+
+    def attend(self, e32: torch.Tensor, xq: torch.Tensor, tau_sem: float, tau_geo: float,
+               beta: float, stats: torch.Tensor) -> torch.Tensor:
+        self._t(e32, torch.float32, (KEY_DIM,))
+        self._t(xq, torch.float32, (4,))
+        self._t(stats, torch.float32, (4,))
+        B = e32.shape[0]
+        out = self._empty((B, VAL_DIM), torch.float32)
+        _check(self.lib, self.lib.range_attend(self._h, e32.data_ptr(), xq.data_ptr(), B, tau_sem,
+                                               tau_geo, beta, stats.data_ptr(), out.data_ptr(),
+                                               self._stream()))
+        return out
+
+    def finalize(self, partials: torch.Tensor, e64: torch.Tensor) -> torch.Tensor:
+        if partials.dim() == 2:
+            partials = partials.unsqueeze(0)
+        P, B = partials.shape[0], partials.shape[1]
+        self._t(partials, torch.float32, (B, VAL_DIM))
+        self._t(e64, torch.float64, (KEY_DIM,))
+        out = self._empty((B, OUT_DIM), torch.float64)
+        _check(self.lib, self.lib.range_finalize(self._h, partials.data_ptr(), P, e64.data_ptr(),
+                                                 B, out.data_ptr(), self._stream()))
+        return out
+
+    def forward(self, lonlat: torch.Tensor, model: int, beta: float,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._t(lonlat, torch.float64, (2,))
+        B = lonlat.shape[0]
+        if out is None:
+            out = self._empty((B, OUT_DIM), torch.float64)
+        else:
+            self._t(out, torch.float64, (OUT_DIM,))
+        _check(self.lib, self.lib.range_forward(self._h, lonlat.data_ptr(), B, model, beta,
+                                                out.data_ptr(), self._stream()))
+        return out
+
+    def last_geometry(self) -> Tuple[int, int]:
+        a, b = C.c_int32(), C.c_int32()
+        _check(self.lib, self.lib.range_last_attend_geometry(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

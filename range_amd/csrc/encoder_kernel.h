@@ -1,0 +1,255 @@
+// Kernel A of the RANGE engine: fused (lon,lat) -> spherical-harmonic features -> SirenNet ->
+// L2 normalisation, all in float64 like the reference (satclip/model_old.py:326-330,
+// range/range.py:83-84, 210-212), plus the query's unit xyz (range/range.py:225-229).
+//
+// Reference ops replaced: spherical_harmonics.py:27-42 (1600 TorchScript launches + stack for
+// L=40), location_encoder.py:98-112 (3 F.linear + 2 sin), range.py:212 (norm + div).
+//
+// Design
+//   * The SH basis is evaluated by the stable three-term recurrence on fully normalised
+//     associated Legendre functions (one chain per order m), with the reference's conventions
+//     folded into the chain seed: "analytic" = sqrt(2) N P cos/sin(m phi) without the
+//     Condon-Shortley sign and pi * orthonormal for m = 0; "closed-form" = orthonormal m = 0 and
+//     the Condon-Shortley sign kept.  The reference's expanded
+//     polynomials are NOT reproduced: they are ill-conditioned in float64 above |lat| ~ 45 deg.
+//   * The features are never written to HBM.  The first layer's K dimension (L*L) is re-ordered
+//     on the host into "slots": slot 0 = order 0, slot s = orders {s, L-s}; every slot is one
+//     thread's work of exactly L recurrence steps for one query, i.e. perfectly balanced.  Four
+//     slots (<= 8L features) are generated per round into LDS and consumed by the MFMAs.
+//   * GEMMs run on v_mfma_f64_16x16x4_f64.  Workgroup = 4 waves = 32 queries; wave w owns hidden
+//     columns [w*H/4, (w+1)*H/4) for both 16-query tiles, so weights are never shared between
+//     waves and stream straight from L2 in pre-packed fragment order (512 B per wave
+//     instruction), while activations go through LDS in fragment order with an XOR swizzle that
+//     keeps both the accumulator write-back and the operand reads bank-conflict free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace range_hip {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ENC_QTILE = 32;
+constexpr int ENC_MAX_LAYERS = 8;      // hidden layers + last
+constexpr int ENC_SLOTS_PER_ROUND = 4;
+constexpr int ENC_EMBED = 256;
+
+struct EncArgs {
+    const double* lonlat;   // (B,2)
+    double* ehat64;         // (B,256)
+    float* ehat32;          // (B,256)
+    float* xq;              // (B,4)
+    int64_t B;
+    int32_t L;
+    int32_t n_slots;
+    int32_t n_rounds;
+    int32_t n_layers;       // hidden layers (>=1); last layer is index n_layers
+    int32_t H;
+    int32_t ks0_total;      // k-steps (of 4) of the padded, permuted first-layer K
+    int32_t lds_main_doubles;
+    const int32_t* slot_base;   // [n_slots+1] padded feature offsets (multiples of 4)
+    const double* coefA;        // [L*L] at l*L+m : a(l,m)            (0 for l<=m)
+    const double* coefB;        // [L*L] at l*L+m : a(l,m)*b(l,m)
+    const double* seedc;        // [L]  chain seed constant incl. convention factors
+    const double* wp[ENC_MAX_LAYERS];     // packed weights, fragment order
+    const double* bias[ENC_MAX_LAYERS];
+};
+
+// LDS address (in doubles) of activation element (query q in 0..31, k) in fragment order:
+// fragment (kstep, qtile) = 64 doubles = the A operand of one MFMA: lane (kq = k&3, ql = q&15).
+// The XOR term spreads the 16 lanes of an accumulator write-back (16 consecutive k, same q)
+// over 16 bank pairs; a fragment read (fixed k, ql = 0..15) stays a contiguous permutation.
+__device__ __forceinline__ int act_addr(int q, int k) {
+    const int kstep = k >> 2, kq = k & 3;
+    return ((kstep * 2 + (q >> 4)) << 6) + (kq << 4) + ((q & 15) ^ ((kq << 2) | (kstep & 3)));
+}
+__device__ __forceinline__ int frag_addr(int kstep, int qt, int lane) {
+    const int kq = lane >> 4;
+    return ((kstep * 2 + qt) << 6) + (kq << 4) + ((lane & 15) ^ ((kq << 2) | (kstep & 3)));
+}
+
+// acc[qt][i] += A(lds, ksteps) x Wp rows owned by this wave (NTW n-tiles), K = 4*ksteps.
+// wp points at this wave's first n-tile, k-step 0, lane element; n-tile stride = ks_stride*64.
+template <int NTW>
+__device__ __forceinline__ void gemm_ksteps(const double* lds, const double* wp, int ksteps,
+                                            int64_t ks_stride, int lane, f64x4 (&acc)[2][NTW]) {
+#pragma unroll 2
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const double a0 = lds[frag_addr(ks, 0, lane)];
+        const double a1 = lds[frag_addr(ks, 1, lane)];
+        double b[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) b[i] = wp[((int64_t)i * ks_stride + ks) * 64];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[i], acc[1][i], 0, 0, 0);
+        }
+    }
+}
+
+// f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
+template <int NTW>
+__device__ __forceinline__ void store_act(double* lds, const double* bias, double w0, int wave,
+                                          int lane, f64x4 (&acc)[2][NTW]) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int n = (wave * NTW + i) * 16 + (lane & 15);
+        const double bn = bias[n];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + (lane >> 4) + 4 * r;
+                lds[act_addr(q, n)] = sin(w0 * (acc[qt][i][r] + bn));
+            }
+    }
+}
+
+template <int NT>   // NT = H / 64 : n-tiles of 16 hidden columns per wave
+__global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    double* red = lds + a.lds_main_doubles;      // [4 waves][32 queries]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t q0 = (int64_t)blockIdx.x * ENC_QTILE;
+    const double DEG = 3.14159265358979323846 / 180.0;
+
+    // ---- SH generator state: thread = (query gq, slot-in-round gslot); threads 128..255 idle
+    const int gq = tid & 31, gslot = tid >> 5;
+    double cx = 0, sx = 0, phi = 0;
+    if (gslot < ENC_SLOTS_PER_ROUND) {
+        const int64_t q = (q0 + gq < a.B) ? q0 + gq : a.B - 1;
+        phi = (a.lonlat[2 * q] + 180.0) * DEG;                    // spherical_harmonics.py:31
+        const double theta = (a.lonlat[2 * q + 1] + 90.0) * DEG;  // :32
+        cx = cos(theta);
+        sx = sin(theta);
+    }
+
+    f64x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
+
+    const int L = a.L;
+    for (int rnd = 0; rnd < a.n_rounds; ++rnd) {
+        const int s_first = rnd * ENC_SLOTS_PER_ROUND;
+        const int s_last = min(s_first + ENC_SLOTS_PER_ROUND, a.n_slots);
+        const int kp0 = a.slot_base[s_first];
+        const int kp1 = a.slot_base[s_last];
+        __syncthreads();   // previous round's fragment reads are done
+        const int slot = s_first + gslot;
+        if (gslot < ENC_SLOTS_PER_ROUND && slot < s_last) {
+            int pos = a.slot_base[slot] - kp0;
+            const int end = a.slot_base[slot + 1] - kp0;
+            const int m_a = slot;
+            const int m_b = (slot > 0 && L - slot > slot) ? L - slot : -1;
+            for (int c = 0; c < 2; ++c) {
+                const int m = c == 0 ? m_a : m_b;
+                if (m < 0) break;
+                double p = 1.0;
+                for (int i = 0; i < m; ++i) p *= sx;
+                const double seed = a.seedc[m] * p;
+                double cm = 1.0, sm = 0.0;
+                if (m > 0) { cm = cos(m * phi); sm = sin(m * phi); }
+                double q1 = 0.0, q2 = 0.0;
+                for (int l = m; l < L; ++l) {
+                    const double v = (l == m) ? seed
+                                              : a.coefA[l * L + m] * cx * q1 - a.coefB[l * L + m] * q2;
+                    q2 = q1; q1 = v;
+                    if (m == 0) {
+                        lds[act_addr(gq, pos++)] = v;
+                    } else {
+                        lds[act_addr(gq, pos++)] = v * cm;
+                        lds[act_addr(gq, pos++)] = v * sm;
+                    }
+                }
+            }
+            for (; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
+        }
+        __syncthreads();
+        const double* wp = a.wp[0] + ((int64_t)(wave * NT) * a.ks0_total + (kp0 >> 2)) * 64 + lane;
+        gemm_ksteps<NT>(lds, wp, (kp1 - kp0) >> 2, a.ks0_total, lane, acc);
+    }
+
+    // ---- hidden layers: h = sin(w0 * (acc + b)), w0 = 30 on the first layer only
+    //      (location_encoder.py:83, 119, 147-150)
+    const int ksH = a.H >> 2;
+    for (int layer = 0; layer < a.n_layers; ++layer) {
+        __syncthreads();   // all waves finished reading the previous operand
+        store_act<NT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
+        __syncthreads();
+        if (layer + 1 < a.n_layers) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
+            const double* wp = a.wp[layer + 1] + ((int64_t)(wave * NT) * ksH) * 64 + lane;
+            gemm_ksteps<NT>(lds, wp, ksH, ksH, lane, acc);
+        }
+    }
+
+    // ---- last layer (Identity activation, location_encoder.py:95-96, 112): 256 outputs,
+    //      4 n-tiles per wave
+    f64x4 ae[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ae[0][i] = f64x4{0, 0, 0, 0}; ae[1][i] = f64x4{0, 0, 0, 0}; }
+    {
+        const double* wp = a.wp[a.n_layers] + ((int64_t)(wave * 4) * ksH) * 64 + lane;
+        gemm_ksteps<4>(lds, wp, ksH, ksH, lane, ae);
+    }
+    const double* bl = a.bias[a.n_layers];
+    double ss[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss[qt][r] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double bn = bl[(wave * 4 + i) * 16 + (lane & 15)];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ae[qt][i][r] += bn;
+                ss[qt][r] += ae[qt][i][r] * ae[qt][i][r];
+            }
+    }
+    // ---- L2 norm over the 256 outputs of each query (range.py:212)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = ss[qt][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if ((lane & 15) == 0) red[wave * 32 + qt * 16 + (lane >> 4) + 4 * r] = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ql = qt * 16 + (lane >> 4) + 4 * r;
+            const double nrm = sqrt(red[ql] + red[32 + ql] + red[64 + ql] + red[96 + ql]);
+            const int64_t q = q0 + ql;
+            if (q < a.B) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = (wave * 4 + i) * 16 + (lane & 15);
+                    const double e = ae[qt][i][r] / nrm;
+                    a.ehat64[q * ENC_EMBED + n] = e;
+                    a.ehat32[q * ENC_EMBED + n] = (float)e;
+                }
+            }
+        }
+    // ---- query unit vector: float64 trig, then .float()  (range.py:225-231, utils.py:11-16)
+    if (tid < ENC_QTILE && q0 + tid < a.B) {
+        const int64_t q = q0 + tid;
+        const double lon = a.lonlat[2 * q] * 3.14159265358979323846 / 180.0;
+        const double lat = a.lonlat[2 * q + 1] * 3.14159265358979323846 / 180.0;
+        const double cl = cos(lat);
+        float4 o = make_float4((float)(cl * cos(lon)), (float)(cl * sin(lon)), (float)sin(lat), 0.f);
+        *reinterpret_cast<float4*>(a.xq + q * 4) = o;
+    }
+}
+
+}  // namespace range_hip

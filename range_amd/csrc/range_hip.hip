@@ -1,0 +1,549 @@
+// librange_hip.so - C ABI (include/range_hip.h) over the hand-written gfx950 kernels.
+// Host side of the engine: context, one-time weight/bank packing, launch geometry, workspace.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/range_hip.h"
+#include "attend_kernels.h"
+#include "encoder_kernel.h"
+
+using namespace range_hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return fail(RANGE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n) return hipSuccess;
+        if (p) {
+            // growth only happens between batches; make sure nothing still reads the old buffer
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return e;
+            (void)hipFree(p);
+            p = nullptr;
+            n = 0;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        hipError_t e = ensure(h.size());
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+}  // namespace
+
+struct range_ctx {
+    int device = 0;
+    int n_cu = 256;
+    // encoder
+    bool has_encoder = false;
+    range_encoder_desc desc{};
+    EncArgs enc{};
+    size_t enc_lds_bytes = 0;
+    DevBuf<int32_t> d_slot_base;
+    DevBuf<double> d_coefA, d_coefB, d_seedc;
+    DevBuf<double> d_wp[ENC_MAX_LAYERS], d_bias[ENC_MAX_LAYERS];
+    // bank
+    bool has_bank = false;
+    int64_t n_rows = 0, n_pad = 0, row_offset = 0;
+    DevBuf<float> d_keys, d_values, d_xyz4;
+    // workspace
+    DevBuf<float> ws_stats_parts, ws_slabs, ws_stats, ws_ehat32, ws_xq, ws_partial, ws_cand_val;
+    DevBuf<int32_t> ws_cand_idx;
+    DevBuf<double> ws_ehat64;
+    int last_qtiles = 0, last_splits = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Number of bank splits (multiple of 8, one family of splits per XCD).  Workgroups of both scan
+// kernels are equal-cost, so the chip runs them in near lock-step "rounds" of n_cu workgroups:
+// pick the smallest split count whose last round is well filled.
+int choose_splits(int n_qtiles, int n_blocks, int n_cu) {
+    int best = 8;
+    double best_eff = -1.0;
+    for (int ns = 8; ns <= 64; ns += 8) {
+        if (ns > 8 && (int64_t)ns * 4 > n_blocks) break;   // keep >= 4 blocks per split
+        const double total = (double)n_qtiles * ns;
+        const double rounds = std::ceil(total / n_cu);
+        double eff = total / (rounds * n_cu);
+        if (rounds < 4) eff *= 0.9;                         // prefer a few rounds: smoother tail
+        if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
+    }
+    return best;
+}
+
+template <typename K>
+int set_dyn_lds(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RANGE_OK;
+}
+
+int launch_encoder(range_ctx* c, const EncArgs& a, hipStream_t s) {
+    const int grid = (int)((a.B + ENC_QTILE - 1) / ENC_QTILE);
+    const size_t lds = c->enc_lds_bytes;
+#define RANGE_ENC_CASE(NT)                                                          \
+    case NT: {                                                                      \
+        int rc = set_dyn_lds(encoder_kernel<NT>, lds);                              \
+        if (rc) return rc;                                                          \
+        hipLaunchKernelGGL(encoder_kernel<NT>, dim3(grid), dim3(256), lds, s, a);   \
+        break;                                                                      \
+    }
+    switch (a.H / 64) {
+        RANGE_ENC_CASE(1)
+        RANGE_ENC_CASE(2)
+        RANGE_ENC_CASE(3)
+        RANGE_ENC_CASE(4)
+        RANGE_ENC_CASE(5)
+        RANGE_ENC_CASE(6)
+        RANGE_ENC_CASE(7)
+        RANGE_ENC_CASE(8)
+        default:
+            return fail(RANGE_ERR_INVALID, "unsupported hidden width %d", a.H);
+    }
+#undef RANGE_ENC_CASE
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* xq, int64_t B,
+                   float tau_sem, float tau_geo) {
+    if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    if (!(tau_sem > 0.f)) return fail(RANGE_ERR_INVALID, "tau_sem must be > 0");
+    const double LOG2E = 1.4426950408889634;
+    a.keys = c->d_keys.p;
+    a.xyz4 = c->d_xyz4.p;
+    a.values = c->d_values.p;
+    a.ehat = ehat32;
+    a.xq = xq;
+    a.B = B;
+    a.n_valid = c->n_rows;
+    a.n_blocks = (int32_t)((c->n_rows + BLK - 1) / BLK);
+    a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
+    a.n_splits = choose_splits(a.n_qtiles, a.n_blocks, c->n_cu);
+    a.k_sem = (float)(tau_sem * LOG2E);
+    a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
+    a.beta = 1.f;
+    a.stats = nullptr;
+    a.out = nullptr;
+    a.cand_val = nullptr;
+    a.cand_idx = nullptr;
+    c->last_qtiles = a.n_qtiles;
+    c->last_splits = a.n_splits;
+    return RANGE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int range_abi_version(void) { return RANGE_ABI_VERSION; }
+const char* range_last_error(void) { return g_err.c_str(); }
+
+int range_create(int device, range_ctx** out) {
+    if (!out) return fail(RANGE_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail(RANGE_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RANGE_ERR_INVALID, "device %d is %s; this library is built for gfx950 only",
+                    device, prop.gcnArchName);
+    range_ctx* c = new (std::nothrow) range_ctx();
+    if (!c) return fail(RANGE_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return RANGE_OK;
+}
+
+void range_destroy(range_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+int64_t range_bank_rows(const range_ctx* ctx) { return ctx ? ctx->n_rows : 0; }
+
+int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* const* weights,
+                      const double* const* biases) {
+    if (!c || !d || !weights || !biases) return fail(RANGE_ERR_INVALID, "null argument");
+    const int L = d->legendre_polys, H = d->hidden, NL = d->num_hidden_layers, E = d->embed_dim;
+    if (L < 1 || L > 64) return fail(RANGE_ERR_INVALID, "legendre_polys %d unsupported (1..64)", L);
+    if (H < 64 || H > 512 || H % 64) return fail(RANGE_ERR_INVALID, "hidden %d unsupported (multiple of 64, <=512)", H);
+    if (NL < 1 || NL + 1 > ENC_MAX_LAYERS) return fail(RANGE_ERR_INVALID, "num_hidden_layers %d unsupported", NL);
+    if (E != ENC_EMBED) return fail(RANGE_ERR_INVALID, "embed_dim %d unsupported (must be 256)", E);
+    if (d->sh_mode != RANGE_SH_ANALYTIC && d->sh_mode != RANGE_SH_CLOSED_FORM)
+        return fail(RANGE_ERR_INVALID, "unknown sh_mode %d", d->sh_mode);
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+
+    // ---- slot plan: permuted + padded first-layer K order
+    // slot 0 = order 0; slot s>=1 = orders {s, L-s} (s < L-s) or {s} (s == L-s)
+    std::vector<int> slot_m_a, slot_m_b;
+    slot_m_a.push_back(0);
+    slot_m_b.push_back(-1);
+    for (int s = 1; s <= L - s && s < L; ++s) {
+        slot_m_a.push_back(s);
+        slot_m_b.push_back(L - s > s ? L - s : -1);
+    }
+    const int n_slots = (int)slot_m_a.size();
+    std::vector<int32_t> slot_base(n_slots + 1, 0);
+    std::vector<int> perm;   // padded position -> original feature index or -1
+    for (int s = 0; s < n_slots; ++s) {
+        slot_base[s] = (int32_t)perm.size();
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int m = c2 == 0 ? slot_m_a[s] : slot_m_b[s];
+            if (m < 0) break;
+            for (int l = m; l < L; ++l) {
+                if (m == 0) perm.push_back(l * l + l);
+                else { perm.push_back(l * l + l + m); perm.push_back(l * l + l - m); }
+            }
+        }
+        while (perm.size() % 4) perm.push_back(-1);
+    }
+    slot_base[n_slots] = (int32_t)perm.size();
+    {   // every feature exactly once
+        std::vector<char> seen(L * L, 0);
+        int cnt = 0;
+        for (int p : perm) if (p >= 0) { if (seen[p]) return fail(RANGE_ERR_INVALID, "internal: perm duplicate"); seen[p] = 1; ++cnt; }
+        if (cnt != L * L) return fail(RANGE_ERR_INVALID, "internal: perm incomplete");
+    }
+    const int Kp = (int)perm.size();
+    const int n_rounds = (n_slots + ENC_SLOTS_PER_ROUND - 1) / ENC_SLOTS_PER_ROUND;
+    int max_round = 0;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int s1 = std::min((r + 1) * ENC_SLOTS_PER_ROUND, n_slots);
+        max_round = std::max(max_round, slot_base[s1] - slot_base[r * ENC_SLOTS_PER_ROUND]);
+    }
+    const int lds_main = ENC_QTILE * std::max(max_round, H);
+    const size_t lds_bytes = (size_t)(lds_main + 4 * ENC_QTILE) * sizeof(double);
+    if (lds_bytes > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS (>160 KiB)", lds_bytes);
+
+    // ---- recurrence tables (float64)
+    std::vector<double> coefA((size_t)L * L, 0.0), coefB((size_t)L * L, 0.0), seedc(L, 0.0);
+    const double PI = 3.14159265358979323846;
+    double cm = std::sqrt(1.0 / (4.0 * PI));
+    for (int m = 0; m < L; ++m) {
+        if (m > 0) cm *= std::sqrt((2.0 * m + 1.0) / (2.0 * m));
+        double scale;
+        if (m == 0) scale = d->sh_mode == RANGE_SH_ANALYTIC ? PI : 1.0;
+        else scale = std::sqrt(2.0) * ((d->sh_mode == RANGE_SH_CLOSED_FORM && (m & 1)) ? -1.0 : 1.0);
+        seedc[m] = cm * scale;
+        for (int l = m + 1; l < L; ++l) {
+            if (l == m + 1) {
+                coefA[(size_t)l * L + m] = std::sqrt(2.0 * m + 3.0);
+                coefB[(size_t)l * L + m] = 0.0;
+            } else {
+                const double a = std::sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
+                const double b = std::sqrt((((double)l - 1.0) * (l - 1.0) - (double)m * m) /
+                                           (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
+                coefA[(size_t)l * L + m] = a;
+                coefB[(size_t)l * L + m] = a * b;
+            }
+        }
+    }
+
+    // ---- weights into MFMA B-fragment order: [(ntile*ksteps + kstep)*64 + lane],
+    //      lane -> W[ntile*16 + (lane&15)][kstep*4 + (lane>>4)]
+    auto pack = [](const double* W, int n_out, int k_in, const std::vector<int>* kperm, int Kpad) {
+        const int ks = Kpad / 4, nt = n_out / 16;
+        std::vector<double> out((size_t)nt * ks * 64);
+        for (int t = 0; t < nt; ++t)
+            for (int s = 0; s < ks; ++s)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int n = t * 16 + (ln & 15);
+                    const int kp = s * 4 + (ln >> 4);
+                    const int k = kperm ? (*kperm)[kp] : kp;
+                    out[((size_t)t * ks + s) * 64 + ln] = k >= 0 ? W[(size_t)n * k_in + k] : 0.0;
+                }
+        return out;
+    };
+    for (int i = 0; i <= NL; ++i) if (!weights[i] || !biases[i]) return fail(RANGE_ERR_INVALID, "weights[%d]/biases[%d] null", i, i);
+    HIP_TRY(c->d_wp[0].upload(pack(weights[0], H, L * L, &perm, Kp)));
+    for (int i = 1; i < NL; ++i) HIP_TRY(c->d_wp[i].upload(pack(weights[i], H, H, nullptr, H)));
+    HIP_TRY(c->d_wp[NL].upload(pack(weights[NL], E, H, nullptr, H)));
+    for (int i = 0; i <= NL; ++i) {
+        const int n = i < NL ? H : E;
+        HIP_TRY(c->d_bias[i].upload(std::vector<double>(biases[i], biases[i] + n)));
+    }
+    HIP_TRY(c->d_slot_base.upload(slot_base));
+    HIP_TRY(c->d_coefA.upload(coefA));
+    HIP_TRY(c->d_coefB.upload(coefB));
+    HIP_TRY(c->d_seedc.upload(seedc));
+
+    EncArgs& a = c->enc;
+    a = EncArgs{};
+    a.L = L;
+    a.n_slots = n_slots;
+    a.n_rounds = n_rounds;
+    a.n_layers = NL;
+    a.H = H;
+    a.ks0_total = Kp / 4;
+    a.lds_main_doubles = lds_main;
+    a.slot_base = c->d_slot_base.p;
+    a.coefA = c->d_coefA.p;
+    a.coefB = c->d_coefB.p;
+    a.seedc = c->d_seedc.p;
+    for (int i = 0; i <= NL; ++i) { a.wp[i] = c->d_wp[i].p; a.bias[i] = c->d_bias[i].p; }
+    c->enc_lds_bytes = lds_bytes;
+    c->desc = *d;
+    c->has_encoder = true;
+    return RANGE_OK;
+}
+
+int range_set_bank(range_ctx* c, const float* keys, const float* values, const float* xyz,
+                   int64_t n_rows, int64_t row_offset) {
+    if (!c || !keys || !values || !xyz) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_rows <= 0) return fail(RANGE_ERR_INVALID, "n_rows must be > 0");
+    if (n_rows >= (int64_t)1 << 31) return fail(RANGE_ERR_INVALID, "n_rows too large");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const int64_t n_pad = (n_rows + BLK - 1) / BLK * BLK;
+    c->has_bank = false;
+    HIP_TRY(c->d_keys.ensure((size_t)n_pad * KEY_DIM));
+    HIP_TRY(c->d_values.ensure((size_t)n_pad * VAL_DIM));
+    HIP_TRY(c->d_xyz4.ensure((size_t)n_pad * 4));
+    HIP_TRY(hipMemset(c->d_keys.p, 0, (size_t)n_pad * KEY_DIM * 4));
+    HIP_TRY(hipMemset(c->d_values.p, 0, (size_t)n_pad * VAL_DIM * 4));
+    HIP_TRY(hipMemset(c->d_xyz4.p, 0, (size_t)n_pad * 16));
+    HIP_TRY(hipMemcpy(c->d_keys.p, keys, (size_t)n_rows * KEY_DIM * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_values.p, values, (size_t)n_rows * VAL_DIM * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(c->d_xyz4.p, 16, xyz, 12, 12, (size_t)n_rows, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    c->n_rows = n_rows;
+    c->n_pad = n_pad;
+    c->row_offset = row_offset;
+    c->has_bank = true;
+    return RANGE_OK;
+}
+
+int range_encode(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
+                 float* xq32, range_stream_t stream) {
+    if (!c || !lonlat || !ehat64 || !ehat32 || !xq32) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->has_encoder) return fail(RANGE_ERR_STATE, "encoder not set (range_set_encoder)");
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    EncArgs a = c->enc;
+    a.lonlat = lonlat;
+    a.ehat64 = ehat64;
+    a.ehat32 = ehat32;
+    a.xq = xq32;
+    a.B = B;
+    return launch_encoder(c, a, (hipStream_t)stream);
+}
+
+int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                     float tau_geo, float* stats, int topk, float* topk_val, int64_t* topk_idx,
+                     range_stream_t stream) {
+    if (!c || !ehat32 || !xq32 || !stats) return fail(RANGE_ERR_INVALID, "null argument");
+    if (topk < 0 || topk > MAX_TOPK) return fail(RANGE_ERR_INVALID, "topk must be in [0,%d]", MAX_TOPK);
+    if (topk > 0 && (!topk_val || !topk_idx)) return fail(RANGE_ERR_INVALID, "topk outputs null");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    ScanArgs a{};
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
+    a.out = c->ws_stats_parts.p;
+    if (topk > 0) {
+        HIP_TRY(c->ws_cand_val.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
+        HIP_TRY(c->ws_cand_idx.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
+        a.cand_val = c->ws_cand_val.p;
+        a.cand_idx = c->ws_cand_idx.p;
+    }
+    const dim3 grid((unsigned)(a.n_splits * a.n_qtiles)), block(256);
+    const bool geo = tau_geo > 0.f;
+#define RANGE_SCAN_LAUNCH(G, T)                                                             \
+    do {                                                                                    \
+        rc = set_dyn_lds(scan_stats_kernel<G, T>, SCAN_LDS_BYTES);                          \
+        if (rc) return rc;                                                                  \
+        hipLaunchKernelGGL((scan_stats_kernel<G, T>), grid, block, SCAN_LDS_BYTES, s, a);   \
+    } while (0)
+    if (geo && topk) RANGE_SCAN_LAUNCH(true, true);
+    else if (geo) RANGE_SCAN_LAUNCH(true, false);
+    else if (topk) RANGE_SCAN_LAUNCH(false, true);
+    else RANGE_SCAN_LAUNCH(false, false);
+#undef RANGE_SCAN_LAUNCH
+    HIP_TRY(hipGetLastError());
+    const int tpb = 256;
+    hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(tpb), 0, s,
+                       c->ws_stats_parts.p, a.n_splits, B, stats);
+    HIP_TRY(hipGetLastError());
+    if (topk > 0) {
+        hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,
+                           c->ws_cand_val.p, c->ws_cand_idx.p, (const int64_t*)nullptr, a.n_splits,
+                           B, 4 * MAX_TOPK, topk, c->row_offset, topk_val, topk_idx);
+        HIP_TRY(hipGetLastError());
+    }
+    return RANGE_OK;
+}
+
+int range_merge_stats(range_ctx* c, const float* parts, int32_t n_parts, int64_t B, float* out,
+                      range_stream_t stream) {
+    if (!c || !parts || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_parts <= 0 || B <= 0) return fail(RANGE_ERR_INVALID, "n_parts and B must be > 0");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const int tpb = 256;
+    hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(tpb), 0,
+                       (hipStream_t)stream, parts, n_parts, B, out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int range_merge_topk(range_ctx* c, const float* val_parts, const int64_t* idx_parts, int32_t n_parts,
+                     int64_t B, int32_t k, float* val_out, int64_t* idx_out, range_stream_t stream) {
+    if (!c || !val_parts || !idx_parts || !val_out || !idx_out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_parts <= 0 || B <= 0 || k <= 0 || k > MAX_TOPK) return fail(RANGE_ERR_INVALID, "bad n_parts/B/k");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0,
+                       (hipStream_t)stream, val_parts, (const int32_t*)nullptr, idx_parts, n_parts, B,
+                       k, k, (int64_t)0, val_out, idx_out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                 float tau_geo, float beta, const float* stats_global, float* partial,
+                 range_stream_t stream) {
+    if (!c || !ehat32 || !xq32 || !stats_global || !partial) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!(beta >= 0.f && beta <= 1.f)) return fail(RANGE_ERR_INVALID, "beta must be in [0,1]");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    ScanArgs a{};
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c->ws_slabs.ensure((size_t)a.n_splits * B * VAL_DIM));
+    a.out = c->ws_slabs.p;
+    a.stats = stats_global;
+    const bool geo = tau_geo > 0.f;
+    a.beta = geo ? beta : 1.f;
+    const dim3 grid((unsigned)(a.n_splits * a.n_qtiles)), block(256);
+    if (geo) {
+        rc = set_dyn_lds(attend_kernel<true>, ATTEND_LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL(attend_kernel<true>, grid, block, ATTEND_LDS_BYTES, s, a);
+    } else {
+        rc = set_dyn_lds(attend_kernel<false>, ATTEND_LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL(attend_kernel<false>, grid, block, ATTEND_LDS_BYTES, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    const int64_t total4 = B * (VAL_DIM / 4);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s,
+                       c->ws_slabs.p, a.n_splits, total4, partial);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const double* ehat64,
+                   int64_t B, double* out, range_stream_t stream) {
+    if (!c || !partials || !ehat64 || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_parts <= 0 || B <= 0) return fail(RANGE_ERR_INVALID, "n_parts and B must be > 0");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const int64_t n = B * 320;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, partials, n_parts, ehat64, B, out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
+                  double* out, range_stream_t stream) {
+    if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
+        return fail(RANGE_ERR_INVALID, "unknown model %d", model);
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    {
+        DeviceGuard g(c->device);
+        if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+        HIP_TRY(c->ws_ehat64.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
+        HIP_TRY(c->ws_stats.ensure((size_t)B * 4));
+        HIP_TRY(c->ws_partial.ensure((size_t)B * VAL_DIM));
+    }
+    const float tau_sem = model == RANGE_MODEL_RANGE ? 15.0f : 12.0f;   // range.py:103, 108
+    const float tau_geo = model == RANGE_MODEL_RANGE ? 0.0f : 40.0f;    // range.py:109
+    int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
+    if (rc) return rc;
+    rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
+                          nullptr, nullptr, stream);
+    if (rc) return rc;
+    rc = range_attend(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
+                      model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, c->ws_partial.p, stream);
+    if (rc) return rc;
+    return range_finalize(c, c->ws_partial.p, 1, c->ws_ehat64.p, B, out, stream);
+}
+
+int range_last_attend_geometry(const range_ctx* c, int32_t* n_query_tiles, int32_t* n_splits) {
+    if (!c) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_query_tiles) *n_query_tiles = c->last_qtiles;
+    if (n_splits) *n_splits = c->last_splits;
+    return RANGE_OK;
+}
+
+}  // extern "C"

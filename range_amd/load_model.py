@@ -1,0 +1,32 @@
+"""``load_model`` - same signature, defaults and error behaviour as the reference's
+range/load_model.py:16-51, for the RANGE / RANGE+ models."""
+from __future__ import annotations
+
+from argparse import Namespace
+
+from .range import LocationEncoder
+
+
+def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwargs):
+    """Load a RANGE / RANGE+ location encoder running on MI355X.
+
+    Args:
+        model_name: 'RANGE' or 'RANGE+'.
+        pretrained_path: SatCLIP checkpoint (e.g. satclip-vit16-l40.ckpt).
+        device: 'cuda' / 'cuda:N'.
+        **kwargs: ``db_path`` (required) - the range_db_*.npz bank; ``beta`` (RANGE+, default 0.5).
+    """
+    if pretrained_path is None:
+        raise ValueError("Please provide the pretrained model path.")      # load_model.py:31-32
+    if "RANGE" in model_name:
+        assert "db_path" in kwargs, "db_path is required for RANGE model."  # :34
+        db_path = kwargs.get("db_path")
+        beta = kwargs.get("beta") if "beta" in kwargs else 0.5             # :37-40
+    else:
+        db_path = None
+        beta = None
+    args = Namespace(location_model_name=model_name, pretrained_path=pretrained_path,
+                     device=device, range_db=db_path, beta=beta)           # :45-46
+    model = LocationEncoder(args)
+    model.eval()
+    return model

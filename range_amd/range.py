@@ -1,0 +1,124 @@
+"""``LocationEncoder`` for RANGE / RANGE+ on MI355X - the drop-in for the reference's
+range/range.py:69-278 (RANGE branches: __init__ :76-114, forward :208-242).
+
+Same constructor contract (an ``argparse.Namespace`` with ``location_model_name``,
+``pretrained_path``, ``device``, ``range_db``, ``beta``), same attributes other code reads
+(``location_feature_dim``, ``args.temp`` / ``args.geo_temp`` / ``args.beta``), same exceptions for
+the same conditions, same call: ``model(coords)`` with ``coords`` a (B,2) float64 tensor of
+(lon, lat) degrees returns a host ``numpy.ndarray`` (B,1280) float64.
+
+All arithmetic runs in hand-written HIP kernels behind librange_hip.so (range_amd/_native.py);
+there is no torch-op or CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native
+from .bank import PreparedBank, load_bank
+from .ckpt import EncoderParams, read_checkpoint
+
+TEMP_RANGE = 15.0        # range/range.py:103
+TEMP_RANGE_PLUS = 12.0   # range/range.py:108
+TEMP_GEO = 40.0          # range/range.py:109
+
+
+def _device_of(spec) -> torch.device:
+    dev = torch.device(spec)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"range_amd runs on MI355X GPUs only (device={spec!r}); there is no CPU path. "
+            "Use the reference implementation for CPU inference.")
+    return dev
+
+
+def make_engine(enc: EncoderParams, bank: PreparedBank, device, row_offset: int = 0):
+    eng = _native.HipEngine(device)
+    mode = _native.SH_ANALYTIC if enc.harmonics_calculation == "analytic" else _native.SH_CLOSED_FORM
+    eng.set_encoder(enc.legendre_polys, enc.hidden, enc.num_hidden_layers, enc.embed_dim, mode,
+                    enc.weights, enc.biases)
+    eng.set_bank(bank.keys, bank.values, bank.xyz, row_offset)
+    return eng
+
+
+class LocationEncoder(nn.Module):
+    """RANGE / RANGE+ retrieval-augmented location encoder (reference: range/range.py:69)."""
+
+    #: queries per engine call; bounds the per-call workspace (split slabs of chunk x 4 KB)
+    chunk_size = 16384
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.location_model_name = args.location_model_name
+        if "RANGE" in self.location_model_name:                        # range.py:76
+            bank = load_bank(args.range_db)                            # :78-95
+            enc = read_checkpoint(args.pretrained_path)                # :82-84
+            if enc.embed_dim != 256:
+                raise ValueError(f"checkpoint embed_dim {enc.embed_dim} != bank key width 256")
+            self.location_feature_dim = 1024 + 256                     # :86
+            if self.location_model_name == "RANGE":                    # :102-105
+                self.args.temp = TEMP_RANGE
+                self._model_id = _native.MODEL_RANGE
+                print(f"Using RANGE with temperature {self.args.temp}")
+            elif self.location_model_name == "RANGE+":                 # :107-112
+                self.args.geo_temp = TEMP_GEO
+                self.args.temp = TEMP_RANGE_PLUS
+                self._model_id = _native.MODEL_RANGE_PLUS
+                print(f"Using RANGE+ with temperatures {self.args.temp} and {self.args.geo_temp}")
+            else:
+                raise ValueError("Unimplemented RANGE model")           # :113-114
+            self.encoder_params = enc
+            self.n_bank_rows = bank.n_rows
+            self._device = _device_of(args.device)
+            self.engine = make_engine(enc, bank, self._device)
+        else:
+            # the reference dispatches 11 more encoder families here (range.py:117-200); they are
+            # unrelated baselines and out of scope for this engine
+            raise NotImplementedError(f"{self.location_model_name} not implemented")
+        self.eval()
+
+    # nn.Module.to()/cuda() must not silently move the engine: the bank lives in the context
+    def _apply(self, fn, recurse=True):
+        return super()._apply(fn, recurse)
+
+    def _coords(self, coords) -> torch.Tensor:
+        if not torch.is_tensor(coords):
+            coords = torch.as_tensor(np.asarray(coords))
+        if coords.dim() != 2 or coords.shape[1] != 2:
+            raise ValueError(f"coords must be (B,2) (lon,lat) degrees, got {tuple(coords.shape)}")
+        # the reference requires float64 input (F.linear against .double() weights);
+        # float32 input is accepted here by widening
+        return coords.to(device=self.engine.device, dtype=torch.float64).contiguous()
+
+    @torch.no_grad()
+    def forward(self, coords, return_device: bool = False):
+        """coords (B,2) float64 (lon,lat) deg -> (B,1280) float64 ``numpy.ndarray`` on the host
+        (range.py:222/240).  ``return_device=True`` returns the device tensor instead (no D2H)."""
+        x = self._coords(coords)
+        B = x.shape[0]
+        beta = 1.0 if self._model_id == _native.MODEL_RANGE else float(self.args.beta)
+        out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
+        for i in range(0, B, self.chunk_size):
+            self.engine.forward(x[i:i + self.chunk_size], self._model_id, beta,
+                                out=out[i:i + self.chunk_size])
+        if return_device:
+            return out
+        return out.cpu().numpy()
+
+    @torch.no_grad()
+    def topk(self, coords, k: int = 16):
+        """Side channel: the k bank rows most similar (cosine, semantic keys) to each query,
+        descending; returns (values (B,k) float32, indices (B,k) int64) device tensors."""
+        x = self._coords(coords)
+        vals, idxs = [], []
+        for i in range(0, x.shape[0], self.chunk_size):
+            _, e32, xq = self.engine.encode(x[i:i + self.chunk_size])
+            _, tv, ti = self.engine.scan_stats(e32, xq, float(self.args.temp), 0.0, topk=k)
+            vals.append(tv)
+            idxs.append(ti)
+        return torch.cat(vals), torch.cat(idxs)

@@ -1,0 +1,138 @@
+"""world_size-2 gloo tests (CPU) of the row-sharded path's collective logic (range_amd/dist.py).
+
+No GPU here, so the per-shard compute is provided by a CHECKER engine built on the CPU oracle
+(allowed in tests only); what is under test is the product's sharding / merge / exchange code:
+all-gather of query operands, exact log-sum-exp merge of shard statistics, all-to-all of the
+partials and the fixed-order finalize, and the single-all-gather top-k merge."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import range_oracle as O
+from range_amd import synth
+from range_amd.dist import ShardedRange, shard_rows
+
+LOG2E = 1.4426950408889634
+
+
+class OracleShardEngine:
+    """Duck-type of _native.HipEngine over one bank shard, float64 math from the oracle."""
+
+    def __init__(self, weights, L, bank: O.Bank, row_offset: int):
+        self.w, self.L, self.bank, self.row_offset = weights, L, bank, row_offset
+
+    def encode(self, lonlat):
+        q = lonlat.numpy()
+        e = O.encode(q, self.w, self.L)
+        xq = np.zeros((q.shape[0], 4), np.float32)
+        xq[:, :3] = O.query_xyz(q)
+        return torch.from_numpy(e), torch.from_numpy(e.astype(np.float32)), torch.from_numpy(xq)
+
+    def _logits(self, e32, xq):
+        s = e32.numpy().astype(np.float64) @ self.bank.keys.astype(np.float64).T
+        g = xq.numpy()[:, :3].astype(np.float64) @ self.bank.xyz.astype(np.float64).T
+        return s, g
+
+    def scan_stats(self, e32, xq, tau_sem, tau_geo, topk=0):
+        s, g = self._logits(e32, xq)
+        st = np.zeros((s.shape[0], 4), np.float64)
+        t = s * tau_sem * LOG2E
+        st[:, 0] = t.max(1); st[:, 1] = np.exp2(t - st[:, :1]).sum(1)
+        if tau_geo > 0:
+            t = g * tau_geo * LOG2E
+            st[:, 2] = t.max(1); st[:, 3] = np.exp2(t - st[:, 2:3]).sum(1)
+        else:
+            st[:, 3] = 1.0
+        st = torch.from_numpy(st.astype(np.float32))
+        if not topk:
+            return st
+        tv, ti = O.topk64(s, topk)
+        return st, torch.from_numpy(tv.astype(np.float32)), torch.from_numpy(ti + self.row_offset)
+
+    def merge_stats(self, parts):
+        p = parts.numpy().astype(np.float64)
+        out = np.zeros(p.shape[1:], np.float64)
+        for c in (0, 2):
+            m = p[:, :, c].max(0)
+            out[:, c] = m
+            out[:, c + 1] = (p[:, :, c + 1] * np.exp2(p[:, :, c] - m)).sum(0)
+        return torch.from_numpy(out.astype(np.float32))
+
+    def attend(self, e32, xq, tau_sem, tau_geo, beta, stats):
+        s, g = self._logits(e32, xq)
+        st = stats.numpy().astype(np.float64)
+        w = beta * np.exp2(s * tau_sem * LOG2E - st[:, :1]) / st[:, 1:2]
+        if tau_geo > 0:
+            w = w + (1 - beta) * np.exp2(g * tau_geo * LOG2E - st[:, 2:3]) / st[:, 3:4]
+        return torch.from_numpy((w @ self.bank.values.astype(np.float64)).astype(np.float32))
+
+    def finalize(self, partials, e64):
+        acc = partials[0].clone()
+        for p in partials[1:]:
+            acc = acc + p
+        return torch.cat([acc.double(), e64], dim=1)
+
+    def merge_topk(self, vals, idxs):
+        W, B, k = vals.shape
+        v = vals.permute(1, 0, 2).reshape(B, W * k).numpy()
+        i = idxs.permute(1, 0, 2).reshape(B, W * k).numpy()
+        order = np.lexsort((i, -v), axis=1)[:, :k]
+        return (torch.from_numpy(np.take_along_axis(v, order, 1)),
+                torch.from_numpy(np.take_along_axis(i, order, 1)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, B, L, H, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        locs, vals, keys = synth.make_bank(N, 11)
+        full = O.prep_bank(locs, vals, keys)
+        r0, r1 = shard_rows(N, world, rank)
+        shard = O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1])
+        w = synth.make_encoder_weights(L, H, 256, 2, 5)
+        q = synth.make_queries(B, seed=100 + rank)
+        for name, beta in (("RANGE+", 0.5), ("RANGE+", 0.0), ("RANGE", None)):
+            model = ShardedRange(OracleShardEngine(w, L, shard, r0), name, beta)
+            out = model(torch.from_numpy(q)).numpy()
+            ref = O.forward(q, w, L, full, name, beta)      # unsharded oracle, own queries
+            err = float(np.abs(out - ref).max())
+            assert out.shape == (B, 1280) and err < 1e-5, (name, beta, err)   # f32 op-order noise of the reference
+        model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5)
+        tv, ti = model.topk(torch.from_numpy(q), 8)
+        s, _ = O.logits64(O.encode(q, w, L), q, full)
+        rv, ri = O.topk64(s, 8)
+        assert np.array_equal(ti.numpy(), ri)
+        np.testing.assert_allclose(tv.numpy(), rv, atol=1e-7)
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        ret[rank] = f"{type(ex).__name__}: {ex}"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_forward_gloo(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), 601, 9, 10, 64, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def test_shard_rows_cover():
+    for n in (1, 7, 100_000):
+        for w in (1, 2, 8):
+            spans = [shard_rows(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))

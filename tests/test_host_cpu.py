@@ -1,0 +1,91 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, loader /
+checkpoint / bank readers mirror the reference's behaviour and errors.  No GPU compute."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import range_oracle as O
+from range_amd import _native, synth
+from range_amd.bank import load_bank, prepare_bank
+from range_amd.ckpt import read_checkpoint
+from range_amd.load_model import load_model
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "range_hip.h")).read()
+    declared = set(re.findall(r"\b(range_[a-z_]+)\s*\(", header))
+    declared -= {"range_ctx", "range_stream_t"}
+    assert declared == set(_native.SYMBOLS)
+    lib = _native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.range_abi_version() == 1
+    assert lib.range_last_error() is not None
+
+
+def test_loader_errors_match_reference(tmp_path):
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 50, 1)
+    with pytest.raises(ValueError):                      # load_model.py:31-32
+        load_model("RANGE+", db_path=db)
+    with pytest.raises(AssertionError):                  # load_model.py:34
+        load_model("RANGE+", pretrained_path=ck)
+    with pytest.raises(ValueError, match="Unimplemented RANGE model"):   # range.py:113-114
+        load_model("RANGE++", pretrained_path=ck, device="cuda", db_path=db)
+    with pytest.raises(NotImplementedError):             # range.py:199-200
+        load_model("NoSuchModel", pretrained_path=ck)
+    if not torch.cuda.is_available():
+        # the product has no CPU path and must say so loudly
+        with pytest.raises(RuntimeError):
+            load_model("RANGE+", pretrained_path=ck, device="cpu", db_path=db)
+        with pytest.raises(RuntimeError):
+            load_model("RANGE+", pretrained_path=ck, device="cuda", db_path=db)
+
+
+def test_checkpoint_reader(tmp_path):
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=16, hidden=128, num_hidden_layers=3,
+                                seed=6, harmonics_calculation="closed-form")
+    p = read_checkpoint(ck)
+    assert (p.legendre_polys, p.hidden, p.num_hidden_layers, p.embed_dim) == (16, 128, 3, 256)
+    assert p.harmonics_calculation == "closed-form"
+    w = synth.make_encoder_weights(16, 128, 256, 3, 6)
+    assert len(p.weights) == 4 and np.array_equal(p.weights[0], w["layers.0.weight"])
+    assert np.array_equal(p.biases[3], w["last_layer.bias"]) and p.weights[3].dtype == np.float64
+    # the three hyper-parameters the reference pops unconditionally (satclip/load.py:5-7)
+    c = synth.make_checkpoint(L=10, hidden=64)
+    del c["hyper_parameters"]["eval_downstream"]
+    torch.save(c, str(tmp_path / "bad.ckpt"))
+    with pytest.raises(KeyError):
+        read_checkpoint(str(tmp_path / "bad.ckpt"))
+    c = synth.make_checkpoint(L=10, hidden=64)
+    c["hyper_parameters"]["le_type"] = "grid"
+    torch.save(c, str(tmp_path / "grid.ckpt"))
+    with pytest.raises(NotImplementedError):
+        read_checkpoint(str(tmp_path / "grid.ckpt"))
+
+
+def test_bank_prep_matches_oracle_bitwise(tmp_path):
+    db = synth.write_bank(str(tmp_path / "db.npz"), 321, 4)
+    b = load_bank(db)
+    o = O.load_bank(db)
+    assert np.array_equal(b.keys, o.keys) and np.array_equal(b.values, o.values)
+    assert np.array_equal(b.xyz, o.xyz)
+    assert b.keys.dtype == b.values.dtype == b.xyz.dtype == np.float32
+    with pytest.raises(ValueError):
+        prepare_bank(np.zeros((3, 2)), np.zeros((3, 1024)), np.zeros((3, 128)))
+    sub = b.rows(10, 20)
+    assert sub.n_rows == 10 and np.array_equal(sub.keys, b.keys[10:20])
+
+
+def test_engine_requires_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_native.RangeNativeError):
+        _native.HipEngine("cuda:0")
+    with pytest.raises(_native.RangeNativeError):
+        _native.HipEngine("cpu")
