@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: geo-embeddings/sec of the RANGE+ forward path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (encode -> stats -> attend -> finalize, i.e.
+``load_model('RANGE+', beta=0.5)(locs)`` up to the device-resident (B,1280) float64 result) over
+one batch of 10 000 synthetic queries per GPU, against the synthetic ``range_db_large`` bank
+(N = 100 000 rows, SatCLIP-L40 encoder with H = 512; shapes are assumptions).
+Inputs are resident in HBM when the timed region starts; the final device->host copy of the
+reference's numpy contract is NOT in the timed region (PCIe-inclusive rate: DESIGN.md).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the bank is row-sharded,
+each rank serves its own 10 000 queries against all shards (range_amd/dist.py) - per-GPU work is
+constant, so the reported scaling is weak.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from range_amd import _native, synth          # noqa: E402
+from range_amd.bank import prepare_bank       # noqa: E402
+
+FLOP_PAIR_ATTEND = 2 * (256 + 3 + 1024)       # pass 2, per (query, bank row): logits + w @ V
+FLOP_PAIR_STATS = 2 * (256 + 3)               # pass 1
+FLOP_PAIR_REFERENCE = 4614                    # the reference's arithmetic
+BANK_ROW_BYTES = (256 + 1024 + 3) * 4         # 5132 B
+PEAK_F32_MATRIX_TFLOPS = 157.3                # MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--bank", default="range_db_large", choices=sorted(synth.BANK_ROWS))
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--beta", type=float, default=0.5)
+    ap.add_argument("--cpu-sample", type=int, default=2048,
+                    help="queries of the same workload timed on the host for cpu_baseline (0=off)")
+    return ap.parse_args()
+
+
+def encoder_params(L, H):
+    from range_amd.ckpt import EncoderParams
+    w = synth.make_encoder_weights(L, H, 256, 2, 1234)
+    return w, EncoderParams(L, H, 2, 256, "analytic",
+                            [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
+                            [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
+
+
+def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
+    """The oracle (CPU restatement of the reference, torch CPU ops in the reference's order and
+    dtypes) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import range_oracle as O     # checker / baseline only
+    locs, vals, keys = bank_arrays
+    obank = O.prep_bank(locs, vals, keys)
+    q = synth.make_queries(n_sample, seed=7)
+    O.forward(q[:64], weights, L, obank, model, beta)          # warm-up
+    t0 = time.perf_counter()
+    O.forward(q, weights, L, obank, model, beta, chunk=512)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "geo-embeddings/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n_sample} of the 10000-query batch, same bank, chunks of 512, "
+                      f"{dt:.1f} s, host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        from range_amd.dist import ShardedRange, init_from_env, shard_rows
+        init_from_env("nccl")
+
+    L, H = 40, a.hidden
+    N = synth.BANK_ROWS[a.bank]
+    weights, enc = encoder_params(L, H)
+    bank_arrays = synth.make_bank(N, 2024)
+    bank = prepare_bank(*bank_arrays)
+    eng = _native.HipEngine(dev)
+    eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
+    if world == 1:
+        eng.set_bank(bank.keys, bank.values, bank.xyz, 0)
+        n_local = N
+    else:
+        r0, r1 = shard_rows(N, world, rank)
+        sh = bank.rows(r0, r1)
+        eng.set_bank(sh.keys, sh.values, sh.xyz, r0)
+        n_local = r1 - r0
+        model = ShardedRange(eng, "RANGE+", a.beta)
+
+    B = a.queries
+    x = torch.from_numpy(synth.make_queries(B, seed=7 + rank)).to(dev)
+    out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+
+    def step():
+        if world == 1:
+            eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+        else:
+            out.copy_(model(x))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    att_ms, att_n = eng.profile_read(_native.RANGE_PROF_ATTEND if hasattr(_native, "RANGE_PROF_ATTEND") else 2)
+    st_ms, st_n = eng.profile_read(1)
+    en_ms, en_n = eng.profile_read(0)
+    eng.profile_enable(False)
+    assert att_n == a.steps, (att_n, a.steps)
+    assert bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        q_per_launch = B * world                      # every rank attends all queries
+        att_avg_ms = att_ms / att_n
+        flops = q_per_launch * n_local * FLOP_PAIR_ATTEND
+        achieved = flops / (att_avg_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "attend_pmc.json")
+        if world == 1 and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        qt, ns = eng.last_geometry()
+        total_q = B * world * a.steps
+        res = {
+            "metric": "geo-embeddings/sec (10k-query batch, range_db_large)",
+            "value": total_q / dt,
+            "unit": "geo-embeddings/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RANGE+ beta={a.beta}, SatCLIP-L40 encoder (H={H}, synthetic "
+                                   f"weights), {a.bank} (synthetic, N={N}), {B} queries per GPU "
+                                   "per step, device-resident in/out",
+                       "bank_rows": N, "queries_per_gpu": B, "hidden": H,
+                       "bank_layout": "single GPU" if world == 1 else f"row-sharded x{world}",
+                       "query_tiles": qt, "bank_splits": ns},
+            "roofline": {"kernel": "attend_kernel<GEO> (pass 2: logits + w@V, f32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
+                         "traffic": traffic,
+                         "avg_launch_ms": att_avg_ms, "launches": att_n,
+                         "flop_per_launch": flops,
+                         "algorithmic_bytes_per_launch": n_local * BANK_ROW_BYTES
+                                                         + q_per_launch * (1040 + 4096)},
+            "kernels_ms_per_step": {"encoder": en_ms / max(en_n, 1), "scan_stats": st_ms / max(st_n, 1),
+                                    "attend": att_avg_ms},
+            "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / (dt / a.steps) / 1e12,
+        }
+        if world == 1 and a.cpu_sample > 0:
+            res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

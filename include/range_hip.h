@@ -137,8 +137,17 @@ int range_finalize(range_ctx* ctx, const float* partials_dev, int32_t n_parts,
 int range_forward(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t model, float beta,
                   double* out_dev, range_stream_t stream);
 
-/* Introspection for the bench harness: names/launch geometry of the last attend launch. */
+/* Introspection for the bench harness: launch geometry of the last scan/attend launch. */
 int range_last_attend_geometry(const range_ctx* ctx, int32_t* n_query_tiles, int32_t* n_splits);
+
+/* Per-kernel device timing with HIP events recorded on the launch stream, around the kernel
+ * launch only (the reference's only timing hook is a host time.time() pair,
+ * range/evaluation/visualize_embeddings.py:101-116).  range_profile_enable(ctx,1) starts
+ * collecting (and clears earlier samples); range_profile_read synchronises with the recorded
+ * events and returns the summed duration and the number of launches of one kernel. */
+enum { RANGE_PROF_ENCODER = 0, RANGE_PROF_SCAN_STATS = 1, RANGE_PROF_ATTEND = 2 };
+int range_profile_enable(range_ctx* ctx, int32_t on);
+int range_profile_read(range_ctx* ctx, int32_t which, double* total_ms, int32_t* launches);
 
 #ifdef __cplusplus
 }

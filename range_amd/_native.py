@@ -26,7 +26,7 @@ SYMBOLS = (
     "range_abi_version", "range_last_error", "range_create", "range_destroy", "range_set_encoder",
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
-    "range_last_attend_geometry",
+    "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
 )
 
 
@@ -71,6 +71,8 @@ def load_library() -> C.CDLL:
     lib.range_finalize.argtypes = [vp, vp, i32, vp, i64, vp, vp]
     lib.range_forward.argtypes = [vp, vp, i64, i32, f32, vp, vp]
     lib.range_last_attend_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.range_profile_enable.argtypes = [vp, i32]
+    lib.range_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i32)]
     for name in SYMBOLS:
         getattr(lib, name)
     if lib.range_abi_version() != 1:
@@ -247,6 +249,16 @@ class HipEngine:
         _check(self.lib, self.lib.range_forward(self._h, lonlat.data_ptr(), B, model, beta,
                                                 out.data_ptr(), self._stream()))
         return out
+
+    def profile_enable(self, on: bool = True) -> None:
+        _check(self.lib, self.lib.range_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, which: int) -> Tuple[float, int]:
+        """(summed device ms, launches) of kernel ``which`` (0 encoder, 1 scan_stats, 2 attend)
+        since profile_enable(); measured with HIP events on the launch stream."""
+        ms, n = C.c_double(), C.c_int32()
+        _check(self.lib, self.lib.range_profile_read(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def last_geometry(self) -> Tuple[int, int]:
         a, b = C.c_int32(), C.c_int32()

@@ -73,7 +73,6 @@ __device__ __forceinline__ int frag_addr(int kstep, int qt, int lane) {
 template <int NTW>
 __device__ __forceinline__ void gemm_ksteps(const double* lds, const double* wp, int ksteps,
                                             int64_t ks_stride, int lane, f64x4 (&acc)[2][NTW]) {
-#pragma unroll 2
     for (int ks = 0; ks < ksteps; ++ks) {
         const double a0 = lds[frag_addr(ks, 0, lane)];
         const double a1 = lds[frag_addr(ks, 1, lane)];

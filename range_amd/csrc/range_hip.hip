@@ -91,7 +91,34 @@ struct range_ctx {
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<double> ws_ehat64;
     int last_qtiles = 0, last_splits = 0;
+    // profiling: event pairs per kernel kind
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[3];
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    ~range_ctx() {
+        for (auto& v : prof) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
 };
+
+namespace {
+// records an event pair around one kernel launch when profiling is on
+struct ProfScope {
+    range_ctx* c; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(range_ctx* c_, int which_, hipStream_t s_) : c(c_), which(which_), s(s_) {
+        if (c->profile) { a = c->get_event(); b = c->get_event(); if (a) (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (a && b) { (void)hipEventRecord(b, s); c->prof[which].emplace_back(a, b); }
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -141,6 +168,7 @@ int launch_encoder(range_ctx* c, const EncArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(encoder_kernel<NT>, dim3(grid), dim3(256), lds, s, a);   \
         break;                                                                      \
     }
+    ProfScope ps(c, RANGE_PROF_ENCODER, s);
     switch (a.H / 64) {
         RANGE_ENC_CASE(1)
         RANGE_ENC_CASE(2)
@@ -419,10 +447,13 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
         if (rc) return rc;                                                                  \
         hipLaunchKernelGGL((scan_stats_kernel<G, T>), grid, block, SCAN_LDS_BYTES, s, a);   \
     } while (0)
-    if (geo && topk) RANGE_SCAN_LAUNCH(true, true);
-    else if (geo) RANGE_SCAN_LAUNCH(true, false);
-    else if (topk) RANGE_SCAN_LAUNCH(false, true);
-    else RANGE_SCAN_LAUNCH(false, false);
+    {
+        ProfScope ps(c, RANGE_PROF_SCAN_STATS, s);
+        if (geo && topk) RANGE_SCAN_LAUNCH(true, true);
+        else if (geo) RANGE_SCAN_LAUNCH(true, false);
+        else if (topk) RANGE_SCAN_LAUNCH(false, true);
+        else RANGE_SCAN_LAUNCH(false, false);
+    }
 #undef RANGE_SCAN_LAUNCH
     HIP_TRY(hipGetLastError());
     const int tpb = 256;
@@ -481,14 +512,17 @@ int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B
     const bool geo = tau_geo > 0.f;
     a.beta = geo ? beta : 1.f;
     const dim3 grid((unsigned)(a.n_splits * a.n_qtiles)), block(256);
-    if (geo) {
-        rc = set_dyn_lds(attend_kernel<true>, ATTEND_LDS_BYTES);
-        if (rc) return rc;
-        hipLaunchKernelGGL(attend_kernel<true>, grid, block, ATTEND_LDS_BYTES, s, a);
-    } else {
-        rc = set_dyn_lds(attend_kernel<false>, ATTEND_LDS_BYTES);
-        if (rc) return rc;
-        hipLaunchKernelGGL(attend_kernel<false>, grid, block, ATTEND_LDS_BYTES, s, a);
+    {
+        ProfScope ps(c, RANGE_PROF_ATTEND, s);
+        if (geo) {
+            rc = set_dyn_lds(attend_kernel<true>, ATTEND_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_kernel<true>, grid, block, ATTEND_LDS_BYTES, s, a);
+        } else {
+            rc = set_dyn_lds(attend_kernel<false>, ATTEND_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_kernel<false>, grid, block, ATTEND_LDS_BYTES, s, a);
+        }
     }
     HIP_TRY(hipGetLastError());
     const int64_t total4 = B * (VAL_DIM / 4);
@@ -537,6 +571,32 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
                       model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, c->ws_partial.p, stream);
     if (rc) return rc;
     return range_finalize(c, c->ws_partial.p, 1, c->ws_ehat64.p, B, out, stream);
+}
+
+int range_profile_enable(range_ctx* c, int32_t on) {
+    if (!c) return fail(RANGE_ERR_INVALID, "null argument");
+    DeviceGuard g(c->device);
+    for (auto& v : c->prof) {
+        for (auto& p : v) { (void)hipEventSynchronize(p.second); c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+        v.clear();
+    }
+    c->profile = on != 0;
+    return RANGE_OK;
+}
+
+int range_profile_read(range_ctx* c, int32_t which, double* total_ms, int32_t* launches) {
+    if (!c || which < 0 || which > 2 || !total_ms || !launches) return fail(RANGE_ERR_INVALID, "bad argument");
+    DeviceGuard g(c->device);
+    double sum = 0.0;
+    for (auto& p : c->prof[which]) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int32_t)c->prof[which].size();
+    return RANGE_OK;
 }
 
 int range_last_attend_geometry(const range_ctx* c, int32_t* n_query_tiles, int32_t* n_splits) {
