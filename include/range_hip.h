@@ -149,6 +149,14 @@ enum { RANGE_PROF_ENCODER = 0, RANGE_PROF_SCAN_STATS = 1, RANGE_PROF_ATTEND = 2 
 int range_profile_enable(range_ctx* ctx, int32_t on);
 int range_profile_read(range_ctx* ctx, int32_t which, double* total_ms, int32_t* launches);
 
+/* Diagnostic only (kernel tuning): range_attend's launch with an instrumented kernel build that
+ * sums, per (workgroup, wave), the shader cycles parked in vmcnt waits / barriers and spent in each
+ * phase; 16 x uint64 per wave into diag_dev (capacity in uint64 words).  Results go to the
+ * internal slabs only.  No reference counterpart. */
+int range_attend_diag(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
+                      float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
+                      unsigned long long* diag_dev, int64_t diag_capacity, range_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

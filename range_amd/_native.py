@@ -27,6 +27,7 @@ SYMBOLS = (
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
+    "range_attend_diag",
 )
 
 
@@ -73,6 +74,7 @@ def load_library() -> C.CDLL:
     lib.range_last_attend_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.range_profile_enable.argtypes = [vp, i32]
     lib.range_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.range_attend_diag.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, i64, vp]
     for name in SYMBOLS:
         getattr(lib, name)
     if lib.range_abi_version() != 1:
@@ -259,6 +261,17 @@ class HipEngine:
         ms, n = C.c_double(), C.c_int32()
         _check(self.lib, self.lib.range_profile_read(self._h, which, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def attend_diag(self, e32, xq, tau_sem, tau_geo, beta, stats) -> torch.Tensor:
+        """Diagnostic kernel build: (workgroups, 4 waves, 16) int64 cycle sums (see range_hip.h)."""
+        B = e32.shape[0]
+        n = ((B + 63) // 64) * 64 * 4 * 16
+        diag = torch.zeros(n, dtype=torch.int64, device=self.device)
+        _check(self.lib, self.lib.range_attend_diag(self._h, e32.data_ptr(), xq.data_ptr(), B,
+                                                    tau_sem, tau_geo, beta, stats.data_ptr(),
+                                                    diag.data_ptr(), n, self._stream()))
+        qt, ns = self.last_geometry()
+        return diag[: qt * ns * 64].reshape(qt * ns, 4, 16)
 
     def last_geometry(self) -> Tuple[int, int]:
         a, b = C.c_int32(), C.c_int32()

@@ -69,6 +69,7 @@ struct ScanArgs {
     float k_sem;           // tau_sem * log2(e)
     float k_geo;           // tau_geo * log2(e)
     float beta;
+    unsigned long long* diag;   // diagnostic build only: per (workgroup, wave) cycle sums
 };
 
 // blockIdx -> (split, query tile); blocks b and b+8 share an XCD, so each XCD gets splits
@@ -100,18 +101,16 @@ __device__ __forceinline__ void load_qfrag(QFrag& f, const float* ehat, const fl
 // fills all 256 AGPRs with the output accumulators, and any further AGPR-form accumulator makes
 // the allocator shuttle ~1000 registers per block through v_accvgpr_read/write.  The logit tile
 // therefore accumulates in VGPRs through these statements.  hipcc pads nothing around an asm
-// MFMA: `s_nop 1` in front covers a VALU-written operand, and qk_block ends with mfma_fence()
-// before any non-MFMA instruction may read the results.
+// MFMA: the operands here come from LDS reads and long-lived registers (never a just-executed
+// VALU write; the first MFMA of a chain still carries `s_nop 1`), and a chain ends with
+// QKAcc::fence() before any non-MFMA instruction may read the results.
 __device__ __forceinline__ void mfma_v_first(f32x4& d, float a, float b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_v(f32x4& d, float a, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
-// 8-pass MFMA result -> VALU read needs 11 wait states; 16 given.
-__device__ __forceinline__ void mfma_fence(f32x4& x, f32x4& y, f32x4& z) {
-    asm volatile("s_nop 15" : "+v"(x), "+v"(y), "+v"(z));
-}
+// (8-pass MFMA result -> VALU read needs 11 wait states: QKAcc::fence gives 16.)
 
 // The query fragments come from ordinary global loads that hipcc counts; "using" them here puts
 // its vmcnt wait for them in front of the main loop.  Otherwise the wait lands at their first use
@@ -127,36 +126,72 @@ __device__ __forceinline__ void pin_qfrag(QFrag& f) {
 // the ds_read_b128 below bank-conflict free.  The k index is consumed in a permuted order that is
 // identical for both operands.  Two accumulation chains hide the 40-cycle dependent-MFMA latency;
 // the SAME summation order is used in both passes so pass 2 reproduces pass 1's logits bit for bit.
+// Accumulators of one transposed logit tile: four independent semantic chains (one per element of
+// the 16-byte K read; a VGPR-accumulator MFMA chain needs ~3 MFMAs of distance to issue back to
+// back) and the geographic tile.  sem(r) is the fixed summation order used by BOTH passes.
+struct QKAcc {
+    f32x4 a0, a1, a2, a3, g;
+    __device__ __forceinline__ float sem(int r) const { return (a0[r] + a1[r]) + (a2[r] + a3[r]); }
+    __device__ __forceinline__ void fence() {   // MFMA results -> VALU readers
+        asm volatile("s_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(g));
+    }
+};
+
+// Per-lane LDS byte offsets of the K-tile reads (relative to the tile): with R = this lane's bank
+// row and chunk index c = 4s + g, the swizzled position is c ^ R = 4(s ^ (R>>2)) + (g ^ (R&3));
+// for s = 4a + b that is base[b] + 256*a bytes, so 4 VGPRs + immediates address all 16 reads.
+struct KAddr {
+    uint32_t b[4];
+    uint32_t x;
+    __device__ __forceinline__ void init(int lane) {
+        const int g = lane >> 4;
+        const int R = pi_row(lane & 15);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+            b[bb] = (uint32_t)(R * (KEY_DIM * 4) + 64 * (bb ^ (R >> 2)) + 16 * (g ^ (R & 3)));
+        x = (uint32_t)((R * 4 + g) * 4);
+    }
+};
+
+struct KFirst { f32x4 k0, k1; float xa; };   // the reads of a tile's first two steps, issued early
+
 template <bool GEO>
-__device__ __forceinline__ void qk_block(const float* kt, const float* xt, const QFrag& f, int lane,
-                                         f32x4& s_sem, f32x4& s_geo) {
-    const int g = lane >> 4;
-    const int R = pi_row(lane & 15);
-    const float* krow = kt + R * KEY_DIM;
-    f32x4 a0, a1, ag = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ KFirst qk_first_reads(const char* kt, const char* xt, const KAddr& ka_) {
+    KFirst r;
+    r.k0 = *reinterpret_cast<const f32x4*>(kt + ka_.b[0]);
+    r.k1 = *reinterpret_cast<const f32x4*>(kt + ka_.b[1]);
+    r.xa = GEO ? *reinterpret_cast<const float*>(xt + ka_.x) : 0.f;
+    return r;
+}
+
+// hook(s) is inlined after the MFMAs of step s (used to start the next phase's LDS reads early).
+template <bool GEO, class Hook>
+__device__ __forceinline__ void qk_mfma(const char* kt, const KFirst& first, const KAddr& ka_,
+                                        const QFrag& f, QKAcc& c, Hook&& hook) {
     // asm statements are scheduling boundaries for hipcc, so the LDS reads stay where the source
-    // puts them: one 16-byte K read (4 k-steps) ahead of the 4 MFMAs that hide its latency.
-    f32x4 kn = *reinterpret_cast<const f32x4*>(krow + ((g ^ R) << 2));
-    float xa = 0.f;
-    if (GEO) xa = xt[R * 4 + g];
+    // puts them: 16-byte K reads (4 k-steps each) two steps ahead of the MFMAs that hide their latency.
+    f32x4 kn = first.k0, kn2 = first.k1;
+    const float xa = first.xa;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const f32x4 ka = kn;
-        if (s < 15) kn = *reinterpret_cast<const f32x4*>(krow + (((4 * (s + 1) + g) ^ R) << 2));
+        kn = kn2;
+        if (s < 14) kn2 = *reinterpret_cast<const f32x4*>(kt + ka_.b[(s + 2) & 3] + 256 * ((s + 2) >> 2));
         if (s == 0) {
-            mfma_v_first(a0, ka.x, f.q[s].x);
-            mfma_v_first(a1, ka.y, f.q[s].y);
+            mfma_v_first(c.a0, ka.x, f.q[s].x);
+            mfma_v_first(c.a1, ka.y, f.q[s].y);
+            mfma_v_first(c.a2, ka.z, f.q[s].z);
+            mfma_v_first(c.a3, ka.w, f.q[s].w);
         } else {
-            mfma_v(a0, ka.x, f.q[s].x);
-            mfma_v(a1, ka.y, f.q[s].y);
+            mfma_v(c.a0, ka.x, f.q[s].x);
+            mfma_v(c.a1, ka.y, f.q[s].y);
+            mfma_v(c.a2, ka.z, f.q[s].z);
+            mfma_v(c.a3, ka.w, f.q[s].w);
         }
-        mfma_v(a0, ka.z, f.q[s].z);
-        mfma_v(a1, ka.w, f.q[s].w);
+        hook(s);
     }
-    if (GEO) mfma_v_first(ag, xa, f.xq);
-    mfma_fence(a0, a1, ag);
-    s_sem = a0 + a1;
-    s_geo = ag;
+    if (GEO) mfma_v_first(c.g, xa, f.xq);
+    else c.g = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // ---- LDS-DMA (global_load_lds) by inline asm -------------------------------------------------
@@ -164,19 +199,17 @@ __device__ __forceinline__ void qk_block(const float* kt, const float* xt, const
 // cannot tell which LDS bytes the DMA writes; that would serialise the whole ring.  In asm the
 // compiler neither counts nor waits for these operations: every wait on them below is a
 // hand-counted s_waitcnt vmcnt(N) followed by a workgroup barrier.  M0 carries the wave-uniform
-// LDS destination; it is written and restored inside the statement that uses it.
+// LDS destination and is written inside the statement that uses it.  It is not restored: nothing
+// else in these kernels uses M0 (gfx9+ DS instructions do not need it, no other LDS-DMA, movrel,
+// GWS or sendmsg), and every statement that needs it sets it.
 // sbase must be wave-uniform (SGPR pair), voff is the per-lane byte offset.
 __device__ __forceinline__ void dma_b128(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                 :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void dma_b32(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2"
+                 :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
 }
 
 // One K tile (16 rows x 1 KB) + its X tile (16 x 4 f32).  Wave w moves rows 4w..4w+3, one
@@ -196,6 +229,23 @@ __device__ __forceinline__ void issue_k_tile(const float* keys, const float* xyz
     dma_b32(xyz4 + row0 * 4, (uint32_t)(lane << 2), xt_lds);
 }
 
+// Piece-wise forms (one DMA each) so that the issue can be spread between MFMAs.
+__device__ __forceinline__ void issue_k_row(const float* keys, int64_t row0, uint32_t kt_lds,
+                                            int wave, int swz, int rr) {
+    const int R = 4 * wave + rr;
+    dma_b128(keys + (row0 + R) * KEY_DIM, (uint32_t)((swz ^ rr) << 4), kt_lds + R * (KEY_DIM * 4));
+}
+__device__ __forceinline__ void issue_x_tile(const float* xyz4, int64_t row0, uint32_t xt_lds,
+                                             int lane) {
+    dma_b32(xyz4 + row0 * 4, (uint32_t)(lane << 2), xt_lds);
+}
+__device__ __forceinline__ void issue_v_piece(const float* values, int64_t row0, uint32_t vslot_lds,
+                                              int wave, int lane, int ii) {
+    const int i = 8 * wave + ii;
+    dma_b128(values + (row0 + (i >> 2)) * VAL_DIM + (i & 3) * 256, (uint32_t)(lane << 4),
+             vslot_lds + i * 1024);
+}
+
 // One 8-row half block of V (32 KB, row-major, linear): 32 pieces of 1 KB, 8 per wave.
 __device__ __forceinline__ void issue_v_half(const float* values, int64_t row0, uint32_t vslot_lds,
                                              int wave, int lane) {
@@ -210,6 +260,25 @@ __device__ __forceinline__ void issue_v_half(const float* values, int64_t row0, 
 // wait for all but the n youngest vector-memory operations of this wave, then workgroup barrier.
 // One asm statement with a memory clobber: no LDS access may be moved across it by the compiler.
 #define RANGE_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+
+// Diagnostic build only (attend_kernel<GEO, true>, never on the product path): s_memtime stamps
+// around the two parts of a wait so that their cycles can be summed per wave.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define RANGE_WAIT_BARRIER_DIAG(n, vm, bar)                                   \
+    do {                                                                      \
+        const unsigned long long t0_ = stamp();                               \
+        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");                 \
+        const unsigned long long t1_ = stamp();                               \
+        asm volatile("s_barrier" ::: "memory");                               \
+        const unsigned long long t2_ = stamp();                               \
+        vm += t1_ - t0_; bar += t2_ - t1_;                                    \
+    } while (0)
+#define RANGE_WB(n, vm, bar)                                                  \
+    do { if (DIAG) RANGE_WAIT_BARRIER_DIAG(n, vm, bar); else RANGE_WAIT_BARRIER(n); } while (0)
 
 
 __device__ __forceinline__ void merge_ml(float& m, float& l, float m2, float l2) {
@@ -248,8 +317,7 @@ struct TopK {
 template <bool GEO, bool TOPK>
 __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* kring = reinterpret_cast<float*>(smem);        // 3 x [16][256]
-    float* xring = kring + 3 * BLK * KEY_DIM;             // 3 x [16][4]
+    // LDS: K ring 3 x [16][256] f32 | X ring 3 x [16][4] f32
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
     const uint32_t kring_lds = lds0, xring_lds = lds0 + 3 * BLK * KEY_DIM * 4;
     constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
@@ -267,8 +335,9 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
 
     QFrag f;
     load_qfrag(f, a.ehat, a.xq, a.B, q, g);
-
     pin_qfrag(f);
+    KAddr kaddr;
+    kaddr.init(lane);
 
     float m1 = NEG_BIG, l1 = 0.f, m2 = NEG_BIG, l2 = 0.f;
     TopK<TOPK ? MAX_TOPK : 1> tk;
@@ -291,8 +360,13 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             issue_k_tile(a.keys, a.xyz4, (int64_t)(b0 + t + 2) * BLK, kring_lds + s2 * KT_BYTES,
                          xring_lds + s2 * 256, wave, lane, swz);
         }
-        f32x4 ss, sg;
-        qk_block<GEO>(kring + slot * BLK * KEY_DIM, xring + slot * 64, f, lane, ss, sg);
+        QKAcc c;
+        qk_mfma<GEO>(smem + slot * KT_BYTES,
+                     qk_first_reads<GEO>(smem + slot * KT_BYTES, smem + 3 * KT_BYTES + slot * 256, kaddr),
+                     kaddr, f, c, [](int) __attribute__((always_inline)) {});
+        c.fence();
+        const f32x4 ss = {c.sem(0), c.sem(1), c.sem(2), c.sem(3)};
+        const f32x4 sg = c.g;
         const int64_t row0 = (int64_t)(b0 + t) * BLK;
         float t1[4], t2[4];
         bool ok[4];
@@ -400,34 +474,86 @@ __device__ __forceinline__ void mfma_a(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-template <int HB>
-__device__ __forceinline__ void pv_half(const float* vslot, const f32x4& w, f32x4 (&acc)[64],
-                                        int lane) {
-    const int j = lane & 15, g = lane >> 4;
-    const float* base = vslot + (2 * g) * VAL_DIM + 4 * j;
-    float w0 = w[2 * HB], w1 = w[2 * HB + 1];
-    asm volatile("s_nop 3" : "+v"(w0), "+v"(w1));   // VALU-written MFMA operands: settle once
-    // lane (j,g) reads V[row 2g+rr][64T + 4j .. +3]: one ds_read_b128 feeds 4 accumulator tiles.
-    // Reads for step T+1 sit in front of step T's 8 MFMAs (256 cycles of cover).
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(base);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM);
+// 8 bank rows x 1024 columns of w @ V for this wave's 16 queries, as 16 steps of 8 MFMAs (4
+// accumulator tiles x 2 rows).  Two devices keep the MFMA pipe fed with one wave per SIMD:
+//  * hook(h), h = 0..59, is inlined after every second MFMA: scalar/vector work placed there in
+//    pieces of <= ~6 instructions (one LDS-DMA for a later tile, a slice of the next block's
+//    softmax weights) issues in the shadow of the 32-cycle MFMAs (an MFMA occupies the issue port
+//    for 8 of its 32 cycles);
+//  * the LAST step of a phase is not executed but handed on as a PvCarry (its V operands are
+//    already in registers): the next phase runs it right after its barrier, behind the first LDS
+//    reads of the new phase, so no LDS latency is exposed at a phase boundary.
+struct PvCarry {
+    f32x4 v0, v1;
+    float w0, w1;
+};
+
+struct PvOps { f32x4 v0, v1; };   // V operands of one step: rows 2g and 2g+1, 4 columns each
+
+// operands of steps 0 and 1 of a half (the read pipeline is two steps deep)
+__device__ __forceinline__ void pv_first_reads(const float* vslot, int lane, PvOps& s0, PvOps& s1) {
+    const float* base = vslot + (2 * (lane >> 4)) * VAL_DIM + 4 * (lane & 15);
+    s0.v0 = *reinterpret_cast<const f32x4*>(base);
+    s0.v1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM);
+    s1.v0 = *reinterpret_cast<const f32x4*>(base + 64);
+    s1.v1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64);
+}
+
+__device__ __forceinline__ void pv_exec_carry(f32x4 (&acc)[64], const PvCarry& c) {
+    mfma_a(acc[60], c.w0, c.v0.x);
+    mfma_a(acc[61], c.w0, c.v0.y);
+    mfma_a(acc[62], c.w0, c.v0.z);
+    mfma_a(acc[63], c.w0, c.v0.w);
+    mfma_a(acc[60], c.w1, c.v1.x);
+    mfma_a(acc[61], c.w1, c.v1.y);
+    mfma_a(acc[62], c.w1, c.v1.z);
+    mfma_a(acc[63], c.w1, c.v1.w);
+}
+
+// steps T = 0..14 of one half; (v0,v1) = operands of step 0 (already requested by the caller);
+// step 15 is returned in `carry`.  hook(h), h = 0..119, runs after MFMA h.  The sched_barriers pin
+// each piece into its own MFMA gap: without them hipcc sinks the pieces behind groups of four
+// MFMAs, where only the last MFMA's shadow (24 issue cycles) is left to hide them.
+#define RANGE_PV_MFMA(tile, w, v, h)                 \
+    mfma_a(acc[tile], w, v);                         \
+    __builtin_amdgcn_sched_barrier(0);               \
+    hook(h);                                         \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <class Hook>
+__device__ __forceinline__ void pv_steps(const float* vslot, float w0, float w1, PvOps s0, PvOps s1,
+                                         f32x4 (&acc)[64], int lane, PvCarry& carry, Hook&& hook) {
+    const float* base = vslot + (2 * (lane >> 4)) * VAL_DIM + 4 * (lane & 15);
+    f32x4 v0 = s0.v0, v1 = s0.v1, n0 = s1.v0, n1 = s1.v1;
 #pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        f32x4 n0 = v0, n1 = v1;
-        if (T < 15) {
-            n0 = *reinterpret_cast<const f32x4*>(base + 64 * (T + 1));
-            n1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64 * (T + 1));
+    for (int T = 0; T < 15; ++T) {
+        // lane (j,g) reads V[row 2g+rr][64T + 4j .. +3]: one ds_read_b128 feeds 4 accumulator
+        // tiles; the reads of step T+2 sit in front of step T's 8 MFMAs (512 cycles of cover)
+        f32x4 m0 = n0, m1 = n1;
+        if (T < 14) {
+            m0 = *reinterpret_cast<const f32x4*>(base + 64 * (T + 2));
+            m1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64 * (T + 2));
         }
-        mfma_a(acc[4 * T + 0], w0, v0.x);
-        mfma_a(acc[4 * T + 1], w0, v0.y);
-        mfma_a(acc[4 * T + 2], w0, v0.z);
-        mfma_a(acc[4 * T + 3], w0, v0.w);
-        mfma_a(acc[4 * T + 0], w1, v1.x);
-        mfma_a(acc[4 * T + 1], w1, v1.y);
-        mfma_a(acc[4 * T + 2], w1, v1.z);
-        mfma_a(acc[4 * T + 3], w1, v1.w);
-        v0 = n0; v1 = n1;
+        RANGE_PV_MFMA(4 * T + 0, w0, v0.x, 8 * T + 0);
+        RANGE_PV_MFMA(4 * T + 1, w0, v0.y, 8 * T + 1);
+        RANGE_PV_MFMA(4 * T + 2, w0, v0.z, 8 * T + 2);
+        RANGE_PV_MFMA(4 * T + 3, w0, v0.w, 8 * T + 3);
+        RANGE_PV_MFMA(4 * T + 0, w1, v1.x, 8 * T + 4);
+        RANGE_PV_MFMA(4 * T + 1, w1, v1.y, 8 * T + 5);
+        RANGE_PV_MFMA(4 * T + 2, w1, v1.z, 8 * T + 6);
+        RANGE_PV_MFMA(4 * T + 3, w1, v1.w, 8 * T + 7);
+        v0 = n0; v1 = n1; n0 = m0; n1 = m1;
     }
+    carry.v0 = v0; carry.v1 = v1; carry.w0 = w0; carry.w1 = w1;
+}
+#undef RANGE_PV_MFMA
+
+// single-instruction f32 add (keeps hipcc from SLP-packing the logit sums into v_pk_add_f32 plus
+// the v_mov shuffles that feed it)
+__device__ __forceinline__ float add1(float x, float y) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 
 // MFMA results -> any non-MFMA reader: wait states first (hipcc pads nothing after an asm MFMA).
@@ -445,12 +571,11 @@ __device__ __forceinline__ void acc_fence(f32x4 (&acc)[64]) {
 constexpr int ATTEND_LDS_BYTES = (3 * 8 * VAL_DIM + 2 * BLK * KEY_DIM + 2 * 64) * 4;
 constexpr int SCAN_LDS_BYTES = (3 * BLK * KEY_DIM + 3 * 64) * 4;
 
-template <bool GEO>
+template <bool GEO, bool DIAG = false>
 __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vring = reinterpret_cast<float*>(smem);          // 3 slots x [8][1024]
-    float* kring = vring + 3 * 8 * VAL_DIM;                 // 2 slots x [16][256]
-    float* xring = kring + 2 * BLK * KEY_DIM;               // 2 slots x [16][4]
+    // then K ring 2 slots x [16][256] and X ring 2 slots x [16][4]
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
     const uint32_t vring_lds = lds0;
@@ -486,43 +611,143 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Vector-memory groups per wave: "even" half h=2t carries V(8) + K(4) + X(1) = 13 LDS-DMA
-    // instructions, "odd" half carries V(8).  Group for half h is issued right after barrier h-2
-    // into V slot h%3 (last read in half h-3) and K/X slot (h/2)&1 (last read in half h-4).
+    KAddr kaddr;
+    kaddr.init(lane);
+    const char* kring_b = smem + 3 * 8 * VAL_DIM * 4;
+    const char* xring_b = kring_b + 2 * BLK * KEY_DIM * 4;
+    // per-lane bank row of accumulator register r, relative to the block, and the number of
+    // valid rows from this split's first row on (pad rows of the last block get weight 0)
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
+    const int n_left = (int)(a.n_valid - (int64_t)b0 * BLK);
+
+    // Schedule (per wave; "half" = 8 bank rows, two per 16-row block t):
+    //   half 2t   : wait+barrier | PV rows 0-7 of block t            (+ issue V half 2t+2)
+    //   half 2t+1 : wait+barrier | QK of block t+1 | PV rows 8-15    (+ issue V half 2t+3,
+    //               K/X tile t+2; the weights of block t+1 are formed between the PV MFMAs)
+    // LDS-DMA groups in issue order: ... E(t-1)=8 | O(t-1)=8+5 | E(t)=8 | O(t)=8+5 ...; the
+    // wait before barrier 2t leaves O(t-1) in flight, the one before barrier 2t+1 leaves E(t).
+    // V half h lives in ring slot h%3 (re-filled two halves after its last read), K/X tile t in
+    // slot t&1.  The steady state is branch-free: past the split's last block the prefetches
+    // re-read that block (clamped) into slots nobody reads any more, so every group has its full
+    // count and the waits are constants.
+    f32x4 w_cur = {0.f, 0.f, 0.f, 0.f};
     if (nb > 0) {
         const int64_t r0 = (int64_t)b0 * BLK;
-        issue_v_half(a.values, r0, vring_lds, wave, lane);
+        const int64_t r1 = (int64_t)(nb > 1 ? b0 + 1 : b0) * BLK;
         issue_k_tile(a.keys, a.xyz4, r0, kring_lds, xring_lds, wave, lane, swz);
+        issue_v_half(a.values, r0, vring_lds, wave, lane);
         issue_v_half(a.values, r0 + 8, vring_lds + VS_BYTES, wave, lane);
-    }
-    int vs = 0;   // V slot of half 2t
-    for (int t = 0; t < nb; ++t) {
-        const int64_t row0 = (int64_t)(b0 + t) * BLK;
-        const bool more = t + 1 < nb;
-        // ---- half 2t: logits + first 8 rows of w @ V
-        RANGE_WAIT_BARRIER(8);
-        const int vs1 = vs == 2 ? 0 : vs + 1;
-        const int vs2 = vs1 == 2 ? 0 : vs1 + 1;
-        if (more) {
-            issue_v_half(a.values, row0 + BLK, vring_lds + vs2 * VS_BYTES, wave, lane);
-            issue_k_tile(a.keys, a.xyz4, row0 + BLK, kring_lds + ((t + 1) & 1) * KT_BYTES,
-                         xring_lds + ((t + 1) & 1) * 256, wave, lane, swz);
-        }
-        f32x4 ss, sg, w;
-        qk_block<GEO>(kring + (t & 1) * BLK * KEY_DIM, xring + (t & 1) * 64, f, lane, ss, sg);
+        issue_k_tile(a.keys, a.xyz4, r1, kring_lds + KT_BYTES, xring_lds + 256, wave, lane, swz);
+        RANGE_WAIT_BARRIER(21);
+        QKAcc c;
+        qk_mfma<GEO>(kring_b, qk_first_reads<GEO>(kring_b, xring_b, kaddr), kaddr, f, c,
+                     [](int) __attribute__((always_inline)) {});
+        c.fence();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool ok = row0 + pi_row(4 * g + r) < a.n_valid;
-            float wr = ca * __builtin_amdgcn_exp2f(fmaf(ss[r], a.k_sem, -m1));
-            if (GEO) wr = fmaf(cb, __builtin_amdgcn_exp2f(fmaf(sg[r], a.k_geo, -m2)), wr);
-            w[r] = ok ? wr : 0.f;
+            float wr = ca * __builtin_amdgcn_exp2f(fmaf(c.sem(r), a.k_sem, -m1));
+            if (GEO) wr = fmaf(cb, __builtin_amdgcn_exp2f(fmaf(c.g[r], a.k_geo, -m2)), wr);
+            w_cur[r] = prow[r] < n_left ? wr : 0.f;
         }
-        pv_half<0>(vring + vs * 8 * VAL_DIM, w, acc, lane);
-        // ---- half 2t+1: last 8 rows
-        if (more) RANGE_WAIT_BARRIER(13); else RANGE_WAIT_BARRIER(0);
-        if (more) issue_v_half(a.values, row0 + BLK + 8, vring_lds + vs * VS_BYTES, wave, lane);
-        pv_half<1>(vring + vs1 * 8 * VAL_DIM, w, acc, lane);
+    }
+    int vs = 0;   // V slot of half 2t
+    PvCarry carry;
+    carry.v0 = carry.v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    carry.w0 = carry.w1 = 0.f;
+    unsigned long long d_vm0 = 0, d_bar0 = 0, d_pv0 = 0, d_vm1 = 0, d_bar1 = 0, d_qk = 0, d_pv1 = 0;
+    unsigned long long d_mark = 0;
+    const unsigned long long d_start = DIAG ? stamp() : 0;
+    const int b_last = b1 - 1;
+    for (int t = 0; t < nb; ++t) {
+        const int vs1 = vs == 2 ? 0 : vs + 1;
+        const int vs2 = vs1 == 2 ? 0 : vs1 + 1;
+        const int bn1 = min(b0 + t + 1, b_last), bn2 = min(b0 + t + 2, b_last);
+        // wave-uniform source / destination bases of this wave's pieces
+        const float* vsrc1 = a.values + ((int64_t)bn1 * BLK + 2 * wave) * VAL_DIM;     // rows 2w, 2w+1
+        const float* ksrc2 = a.keys + ((int64_t)bn2 * BLK + 4 * wave) * KEY_DIM;       // rows 4w..4w+3
+        const float* xsrc2 = a.xyz4 + (int64_t)bn2 * BLK * 4;
+        const uint32_t vdst_e = vring_lds + vs2 * VS_BYTES + wave * 8192;   // half 2t+2
+        const uint32_t vdst_o = vring_lds + vs * VS_BYTES + wave * 8192;    // half 2t+3
+        const uint32_t kdst = kring_lds + (t & 1) * KT_BYTES + wave * 4096;
+        const uint32_t xdst = xring_lds + (t & 1) * 256;
+        const uint32_t vvoff = (uint32_t)(lane << 4);
+        // ---- half 2t
+        RANGE_WB(13, d_vm0, d_bar0);
+        if (DIAG) d_mark = stamp();
+        {
+            PvOps s0, s1;
+            pv_first_reads(vring + vs * 8 * VAL_DIM, lane, s0, s1);
+            pv_exec_carry(acc, carry);                       // last step of the previous half
+            pv_steps(vring + vs * 8 * VAL_DIM, w_cur[0], w_cur[1], s0, s1, acc, lane, carry,
+                     [&](int h) __attribute__((always_inline)) {
+                         if ((h & 15) == 3) {                // 8 pieces: V half 2t+2
+                             const int ii = h >> 4;
+                             dma_b128(vsrc1 + ii * 256, vvoff, vdst_e + ii * 1024);
+                         }
+                     });
+        }
+        // ---- half 2t+1
+        if (DIAG) d_pv0 += stamp() - d_mark;
+        RANGE_WB(8, d_vm1, d_bar1);
+        if (DIAG) d_mark = stamp();
+        QKAcc c;
+        PvOps s0, s1;
+        {
+            const char* kt = kring_b + ((t + 1) & 1) * KT_BYTES;
+            const KFirst kf = qk_first_reads<GEO>(kt, xring_b + ((t + 1) & 1) * 256, kaddr);
+            pv_exec_carry(acc, carry);                       // last step of half 2t
+            qk_mfma<GEO>(kt, kf, kaddr, f, c, [&](int s_) __attribute__((always_inline)) {
+                if (s_ == 13) pv_first_reads(vring + vs1 * 8 * VAL_DIM, lane, s0, s1);
+            });
+        }
+        if (DIAG) { const unsigned long long x_ = stamp(); d_qk += x_ - d_mark; d_mark = x_; }
+        f32x4 w_next = {0.f, 0.f, 0.f, 0.f};
+        float e1[4], e2[4];
+        const int n_left1 = n_left - (t + 1) * BLK;
+        pv_steps(vring + vs1 * 8 * VAL_DIM, w_cur[2], w_cur[3], s0, s1, acc, lane, carry,
+                [&](int h) __attribute__((always_inline)) {
+                    if ((h & 7) == 3) {
+                        const int ii = h >> 3;               // 13 pieces: V half 2t+3, K/X tile t+2
+                        if (ii < 8) dma_b128(vsrc1 + 8 * VAL_DIM + ii * 256, vvoff, vdst_o + ii * 1024);
+                        else if (ii < 12) dma_b128(ksrc2 + (ii - 8) * KEY_DIM, (uint32_t)((swz ^ (ii - 8)) << 4),
+                                                   kdst + (ii - 8) * 1024);
+                        else if (ii == 12) dma_b32(xsrc2, (uint32_t)(lane << 2), xdst);
+                    } else if (h >= 21 && h < 101 && ((h - 21) & 3) == 0) {
+                        // weights of block t+1 in 20 slices of <= 4 VALU instructions; the first
+                        // runs >= 20 MFMAs after the last QK MFMA, whose results are long readable
+                        const int k = (h - 21) >> 2, r = k / 5, part = k % 5;
+                        if (part == 0) {
+                            e1[r] = add1(c.a0[r], c.a1[r]);
+                            e2[r] = add1(c.a2[r], c.a3[r]);
+                        } else if (part == 1) {
+                            e1[r] = fmaf(add1(e1[r], e2[r]), a.k_sem, -m1);
+                            if (GEO) e2[r] = fmaf(c.g[r], a.k_geo, -m2);
+                        } else if (part == 2) {
+                            e1[r] = __builtin_amdgcn_exp2f(e1[r]);
+                        } else if (part == 3) {
+                            if (GEO) e2[r] = __builtin_amdgcn_exp2f(e2[r]);
+                        } else {
+                            float wr = ca * e1[r];
+                            if (GEO) wr = fmaf(cb, e2[r], wr);
+                            w_next[r] = prow[r] < n_left1 ? wr : 0.f;
+                        }
+                    }
+                });
+        if (DIAG) d_pv1 += stamp() - d_mark;
+        w_cur = w_next;
         vs = vs2;
+    }
+    if (nb > 0) pv_exec_carry(acc, carry);   // last step of the last half
+    // the clamped prefetches of the last iterations are still in flight into this workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DIAG && lane == 0 && a.diag) {
+        unsigned long long* d = a.diag + ((size_t)blockIdx.x * 4 + wave) * 16;
+        d[0] = d_vm0; d[1] = d_bar0; d[2] = d_pv0; d[3] = d_vm1; d[4] = d_bar1; d[5] = d_qk;
+        d[6] = d_pv1; d[7] = stamp() - d_start; d[8] = (unsigned long long)nb; d[9] = d_start;
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[10] = xcc & 0xf;
     }
 
     acc_fence(acc);

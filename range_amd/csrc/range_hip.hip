@@ -532,6 +532,32 @@ int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B
     return RANGE_OK;
 }
 
+// Diagnostic (not part of the product path): same launch as range_attend with the instrumented
+// kernel build; diag_dev receives 16 x uint64 per (workgroup, wave): cycles parked in vmcnt waits,
+// barriers, and spent in the PV / QK phases.  Outputs go to the split slabs only.
+int range_attend_diag(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                      float tau_geo, float beta, const float* stats_global,
+                      unsigned long long* diag_dev, int64_t diag_capacity, range_stream_t stream) {
+    if (!c || !ehat32 || !xq32 || !stats_global || !diag_dev) return fail(RANGE_ERR_INVALID, "null argument");
+    DeviceGuard g(c->device);
+    ScanArgs a{};
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    if (rc) return rc;
+    if (!(tau_geo > 0.f)) return fail(RANGE_ERR_INVALID, "diagnostic build exists for the geo variant only");
+    if ((int64_t)a.n_splits * a.n_qtiles * 4 * 16 > diag_capacity) return fail(RANGE_ERR_INVALID, "diag buffer too small");
+    HIP_TRY(c->ws_slabs.ensure((size_t)a.n_splits * B * VAL_DIM));
+    a.out = c->ws_slabs.p;
+    a.stats = stats_global;
+    a.beta = beta;
+    a.diag = diag_dev;
+    rc = set_dyn_lds(attend_kernel<true, true>, ATTEND_LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attend_kernel<true, true>), dim3((unsigned)(a.n_splits * a.n_qtiles)), dim3(256),
+                       ATTEND_LDS_BYTES, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
 int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const double* ehat64,
                    int64_t B, double* out, range_stream_t stream) {
     if (!c || !partials || !ehat64 || !out) return fail(RANGE_ERR_INVALID, "null argument");
