@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
         merge_ml(m1, l1, __shfl_xor(m1, off), __shfl_xor(l1, off));
         if (GEO) merge_ml(m2, l2, __shfl_xor(m2, off), __shfl_xor(l2, off));
     }
-    if (!GEO) { m2 = 0.f; l2 = 1.f; }
+    if (!GEO) { m2 = NEG_BIG; l2 = 0.f; }   // "no rows": stays so under any merge
     if (q < a.B) {
         if (g == 0) {
             f32x4 o = {m1, l1, m2, l2};

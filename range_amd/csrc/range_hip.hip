@@ -135,16 +135,19 @@ struct DeviceGuard {
 };
 
 // Number of bank splits (multiple of 8, one family of splits per XCD).  Workgroups of both scan
-// kernels are equal-cost, so the chip runs them in near lock-step "rounds" of n_cu workgroups:
-// pick the smallest split count whose last round is well filled.
-int choose_splits(int n_qtiles, int n_blocks, int n_cu) {
+// kernels are equal-cost, so the chip runs them in near lock-step "rounds" of n_cu * wg_per_cu
+// workgroups: pick the split count whose last round is best filled, preferring fewer splits
+// (less partial-result traffic) on ties.  wg_per_cu: 1 for pass 2 (512 registers, 129 KB LDS),
+// 3 for pass 1 (49 KB LDS).
+int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits) {
+    const double slots = (double)n_cu * wg_per_cu;
     int best = 8;
     double best_eff = -1.0;
-    for (int ns = 8; ns <= 64; ns += 8) {
+    for (int ns = 8; ns <= max_splits; ns += 8) {
         if (ns > 8 && (int64_t)ns * 4 > n_blocks) break;   // keep >= 4 blocks per split
         const double total = (double)n_qtiles * ns;
-        const double rounds = std::ceil(total / n_cu);
-        double eff = total / (rounds * n_cu);
+        const double rounds = std::ceil(total / slots);
+        double eff = total / (rounds * slots);
         if (rounds < 4) eff *= 0.9;                         // prefer a few rounds: smoother tail
         if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
     }
@@ -187,7 +190,7 @@ int launch_encoder(range_ctx* c, const EncArgs& a, hipStream_t s) {
 }
 
 int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* xq, int64_t B,
-                   float tau_sem, float tau_geo) {
+                   float tau_sem, float tau_geo, bool pass1, int p1_max_splits = 128) {
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
     if (!(tau_sem > 0.f)) return fail(RANGE_ERR_INVALID, "tau_sem must be > 0");
@@ -201,7 +204,9 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.n_valid = c->n_rows;
     a.n_blocks = (int32_t)((c->n_rows + BLK - 1) / BLK);
     a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
-    a.n_splits = choose_splits(a.n_qtiles, a.n_blocks, c->n_cu);
+    // pass 1 writes 16 B per (query, split): many splits are free; pass 2 writes a 4 KB row
+    a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 3, p1_max_splits)
+                       : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1, 64);
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
     a.beta = 1.f;
@@ -209,8 +214,10 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.out = nullptr;
     a.cand_val = nullptr;
     a.cand_idx = nullptr;
-    c->last_qtiles = a.n_qtiles;
-    c->last_splits = a.n_splits;
+    if (!pass1) {
+        c->last_qtiles = a.n_qtiles;
+        c->last_splits = a.n_splits;
+    }
     return RANGE_OK;
 }
 
@@ -428,7 +435,8 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
-    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    // top-k candidates cost 512 B per (query, split): keep the split count low in that variant
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true, topk > 0 ? 16 : 128);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
@@ -503,7 +511,7 @@ int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
-    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, false);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c->ws_slabs.ensure((size_t)a.n_splits * B * VAL_DIM));
@@ -541,7 +549,7 @@ int range_attend_diag(range_ctx* c, const float* ehat32, const float* xq32, int6
     if (!c || !ehat32 || !xq32 || !stats_global || !diag_dev) return fail(RANGE_ERR_INVALID, "null argument");
     DeviceGuard g(c->device);
     ScanArgs a{};
-    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo);
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, false);
     if (rc) return rc;
     if (!(tau_geo > 0.f)) return fail(RANGE_ERR_INVALID, "diagnostic build exists for the geo variant only");
     if ((int64_t)a.n_splits * a.n_qtiles * 4 * 16 > diag_capacity) return fail(RANGE_ERR_INVALID, "diag buffer too small");

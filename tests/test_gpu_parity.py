@@ -232,7 +232,8 @@ def test_row_sharded_merge_matches_single(tmp_path):
         parts = torch.stack([a.scan_stats(e32, xq, tau_sem, tau_geo),
                              b.scan_stats(e32, xq, tau_sem, tau_geo)])
         st = full.merge_stats(parts)
-        lse = lambda s: (s[:, 0::2] + torch.log2(s[:, 1::2]))
+        ncol = 4 if tau_geo > 0 else 2            # the geo statistics are unused for plain RANGE
+        lse = lambda s: (s[:, 0:ncol:2] + torch.log2(s[:, 1:ncol:2]))
         torch.testing.assert_close(lse(st), lse(st_full), rtol=0, atol=2e-5)
         pa = a.attend(e32, xq, tau_sem, tau_geo, beta, st)
         pb = b.attend(e32, xq, tau_sem, tau_geo, beta, st)
@@ -302,3 +303,35 @@ def test_errors_and_edge_cases():
     bs = [bad["layers.0.bias"], bad["layers.1.bias"], bad["last_layer.bias"]]
     with pytest.raises(_native.RangeNativeError):
         eng.set_encoder(10, 96, 2, 256, 0, ws, bs)                     # H not a multiple of 64
+
+
+def test_sharded_path_over_rccl_world1(tmp_path):
+    """The row-sharded forward (range_amd/dist.py) over the RCCL backend.  Only one GPU is
+    available to the test box, so world_size is 1: this exercises the collective calls
+    (all_gather_into_tensor, all_to_all_single on device tensors) and the shard bookkeeping on the
+    real engine; world_size 2/3 run on CPU with gloo (tests/test_dist_cpu.py)."""
+    import torch.distributed as dist
+    from range_amd.dist import ShardedRange
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, B = 2000, 130
+        bank, obank, w, enc, q, e = _synthetic_case(N, B)
+        eng = _engine(enc, bank)
+        x = _dev(q)
+        for name, beta in (("RANGE+", 0.5), ("RANGE", None)):
+            out = ShardedRange(eng, name, beta)(x).cpu().numpy()
+            ref = O.forward(q, w, 10, obank, name, beta)
+            np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+            single = eng.forward(x, _native.MODEL_RANGE_PLUS if name == "RANGE+" else _native.MODEL_RANGE,
+                                 1.0 if beta is None else beta).cpu().numpy()
+            np.testing.assert_allclose(out, single, rtol=0, atol=0)
+        tv, ti = ShardedRange(eng, "RANGE+", 0.5).topk(x, 8)
+        s, _ = O.logits64(e, q, obank)
+        _topk_ok(ti.cpu().numpy(), tv.cpu().numpy(), s, 8)
+    finally:
+        dist.destroy_process_group()
