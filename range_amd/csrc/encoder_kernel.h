@@ -45,13 +45,13 @@ struct EncArgs {
     int32_t n_rounds;
     int32_t n_layers;       // hidden layers (>=1); last layer is index n_layers
     int32_t H;
-    int32_t ks0_total;      // k-steps (of 4) of the padded, permuted first-layer K
+    int32_t kp0_total;      // k-step PAIRS (8 features) of the padded, permuted first-layer K
     int32_t lds_main_doubles;
-    const int32_t* slot_base;   // [n_slots+1] padded feature offsets (multiples of 4)
+    const int32_t* slot_base;   // [n_slots+1] padded feature offsets (multiples of 8)
     const double* coefA;        // [L*L] at l*L+m : a(l,m)            (0 for l<=m)
     const double* coefB;        // [L*L] at l*L+m : a(l,m)*b(l,m)
     const double* seedc;        // [L]  chain seed constant incl. convention factors
-    const double* wp[ENC_MAX_LAYERS];     // packed weights, fragment order
+    const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
 
@@ -68,21 +68,82 @@ __device__ __forceinline__ int frag_addr(int kstep, int qt, int lane) {
     return ((kstep * 2 + qt) << 6) + (kq << 4) + ((lane & 15) ^ ((kq << 2) | (kstep & 3)));
 }
 
-// acc[qt][i] += A(lds, ksteps) x Wp rows owned by this wave (NTW n-tiles), K = 4*ksteps.
-// wp points at this wave's first n-tile, k-step 0, lane element; n-tile stride = ks_stride*64.
+// acc[qt][i] += A(lds, 2*kpairs k-steps) x Wp rows owned by this wave (NTW n-tiles).
+// Weights are packed per PAIR of k-steps: element [(ntile*kp_total + kpair)*64 + lane] is a
+// double2 {W[n][8*kpair + (lane>>4)], W[n][8*kpair + 4 + (lane>>4)]}, n = ntile*16 + (lane&15):
+// one 16-byte load per lane (1 KB per wave instruction) feeds two MFMA k-steps.
+// wp points at this wave's first n-tile, pair 0, lane element; n-tile stride = kp_stride*64.
+// The fragments come straight from L2 / Infinity Cache (each wave owns its n-tiles, nothing to
+// share through LDS): one pair is 32 f64 MFMAs = 2048 cycles, less than that latency under load,
+// so the loads run ENC_PF pairs ahead in a statically indexed register ring.
+constexpr int ENC_PF = 3;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// kp_rot rotates the order in which the pairs are visited (pair index = (i + kp_rot) mod kpairs):
+// every workgroup streams the SAME weights, and without a per-workgroup rotation they all ask the
+// same L2 lines at the same moment.
 template <int NTW>
-__device__ __forceinline__ void gemm_ksteps(const double* lds, const double* wp, int ksteps,
-                                            int64_t ks_stride, int lane, f64x4 (&acc)[2][NTW]) {
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const double a0 = lds[frag_addr(ks, 0, lane)];
-        const double a1 = lds[frag_addr(ks, 1, lane)];
-        double b[NTW];
+__device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, int kpairs,
+                                            int64_t kp_stride, int kp_rot, int lane,
+                                            f64x4 (&acc)[2][NTW]) {
+    auto rot = [&](int i) __attribute__((always_inline)) {
+        i += kp_rot;
+        return i >= kpairs ? i - kpairs : i;
+    };
+    const int ks_base = 0;
+    f64x2 bq[ENC_PF][NTW];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) b[i] = wp[((int64_t)i * ks_stride + ks) * 64];
+    for (int d = 0; d < ENC_PF; ++d) {
+        const int kp = rot(d < kpairs ? d : kpairs - 1);
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[i], acc[0][i], 0, 0, 0);
-            acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[i], acc[1][i], 0, 0, 0);
+        for (int i = 0; i < NTW; ++i) bq[d][i] = wp[((int64_t)i * kp_stride + kp) * 64];
+    }
+    int kp0 = 0;
+    for (; kp0 + ENC_PF <= kpairs; kp0 += ENC_PF) {
+#pragma unroll
+        for (int d = 0; d < ENC_PF; ++d) {
+            const int kp = rot(kp0 + d);
+            const int ks = ks_base + 2 * kp;
+            const double a00 = lds[frag_addr(ks, 0, lane)];
+            const double a01 = lds[frag_addr(ks, 1, lane)];
+            const double a10 = lds[frag_addr(ks + 1, 0, lane)];
+            const double a11 = lds[frag_addr(ks + 1, 1, lane)];
+            f64x2 b[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) b[i] = bq[d][i];
+            // refill this ring slot with pair kp + ENC_PF (clamped: the tail re-reads the last)
+            const int kn = rot(kp0 + d + ENC_PF < kpairs ? kp0 + d + ENC_PF : kpairs - 1);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) bq[d][i] = wp[((int64_t)i * kp_stride + kn) * 64];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, b[i].x, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b[i].x, acc[1][i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, b[i].y, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b[i].y, acc[1][i], 0, 0, 0);
+            }
+        }
+    }
+    // remainder (< ENC_PF pairs): their fragments are already in the ring, in order
+#pragma unroll
+    for (int d = 0; d < ENC_PF - 1; ++d) {
+        if (kp0 + d < kpairs) {
+            const int kp = rot(kp0 + d);
+            const int ks = ks_base + 2 * kp;
+            const double a00 = lds[frag_addr(ks, 0, lane)];
+            const double a01 = lds[frag_addr(ks, 1, lane)];
+            const double a10 = lds[frag_addr(ks + 1, 0, lane)];
+            const double a11 = lds[frag_addr(ks + 1, 1, lane)];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, bq[d][i].x, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, bq[d][i].x, acc[1][i], 0, 0, 0);
+                acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, bq[d][i].y, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, bq[d][i].y, acc[1][i], 0, 0, 0);
+            }
         }
     }
 }
@@ -132,7 +193,9 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
     for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
 
     const int L = a.L;
-    for (int rnd = 0; rnd < a.n_rounds; ++rnd) {
+    for (int rnd_i = 0; rnd_i < a.n_rounds; ++rnd_i) {
+        // rounds are visited in a per-workgroup rotated order (same reason as kp_rot)
+        const int rnd = (int)((rnd_i + blockIdx.x) % (unsigned)a.n_rounds);
         const int s_first = rnd * ENC_SLOTS_PER_ROUND;
         const int s_last = min(s_first + ENC_SLOTS_PER_ROUND, a.n_slots);
         const int kp0 = a.slot_base[s_first];
@@ -168,13 +231,14 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
             for (; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
         }
         __syncthreads();
-        const double* wp = a.wp[0] + ((int64_t)(wave * NT) * a.ks0_total + (kp0 >> 2)) * 64 + lane;
-        gemm_ksteps<NT>(lds, wp, (kp1 - kp0) >> 2, a.ks0_total, lane, acc);
+        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
+                          ((int64_t)(wave * NT) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
+        gemm_kpairs<NT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
     }
 
     // ---- hidden layers: h = sin(w0 * (acc + b)), w0 = 30 on the first layer only
     //      (location_encoder.py:83, 119, 147-150)
-    const int ksH = a.H >> 2;
+    const int kpH = a.H >> 3;
     for (int layer = 0; layer < a.n_layers; ++layer) {
         __syncthreads();   // all waves finished reading the previous operand
         store_act<NT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
@@ -182,8 +246,9 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
         if (layer + 1 < a.n_layers) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
-            const double* wp = a.wp[layer + 1] + ((int64_t)(wave * NT) * ksH) * 64 + lane;
-            gemm_ksteps<NT>(lds, wp, ksH, ksH, lane, acc);
+            const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[layer + 1]) +
+                              ((int64_t)(wave * NT) * kpH) * 64 + lane;
+            gemm_kpairs<NT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, acc);
         }
     }
 
@@ -193,8 +258,9 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ae[0][i] = f64x4{0, 0, 0, 0}; ae[1][i] = f64x4{0, 0, 0, 0}; }
     {
-        const double* wp = a.wp[a.n_layers] + ((int64_t)(wave * 4) * ksH) * 64 + lane;
-        gemm_ksteps<4>(lds, wp, ksH, ksH, lane, ae);
+        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) +
+                          ((int64_t)(wave * 4) * kpH) * 64 + lane;
+        gemm_kpairs<4>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, ae);
     }
     const double* bl = a.bias[a.n_layers];
     double ss[2][4];

@@ -292,7 +292,7 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
                 else { perm.push_back(l * l + l + m); perm.push_back(l * l + l - m); }
             }
         }
-        while (perm.size() % 4) perm.push_back(-1);
+        while (perm.size() % 8) perm.push_back(-1);   // whole k-step pairs (8 features)
     }
     slot_base[n_slots] = (int32_t)perm.size();
     {   // every feature exactly once
@@ -336,19 +336,20 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
         }
     }
 
-    // ---- weights into MFMA B-fragment order: [(ntile*ksteps + kstep)*64 + lane],
-    //      lane -> W[ntile*16 + (lane&15)][kstep*4 + (lane>>4)]
+    // ---- weights into MFMA B-fragment order, two k-steps per 16-byte lane element:
+    //      [((ntile*kpairs + kpair)*64 + lane)*2 + e] = W[ntile*16 + (lane&15)][kpair*8 + 4e + (lane>>4)]
     auto pack = [](const double* W, int n_out, int k_in, const std::vector<int>* kperm, int Kpad) {
-        const int ks = Kpad / 4, nt = n_out / 16;
-        std::vector<double> out((size_t)nt * ks * 64);
+        const int kp = Kpad / 8, nt = n_out / 16;
+        std::vector<double> out((size_t)nt * kp * 128);
         for (int t = 0; t < nt; ++t)
-            for (int s = 0; s < ks; ++s)
-                for (int ln = 0; ln < 64; ++ln) {
-                    const int n = t * 16 + (ln & 15);
-                    const int kp = s * 4 + (ln >> 4);
-                    const int k = kperm ? (*kperm)[kp] : kp;
-                    out[((size_t)t * ks + s) * 64 + ln] = k >= 0 ? W[(size_t)n * k_in + k] : 0.0;
-                }
+            for (int s = 0; s < kp; ++s)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int e = 0; e < 2; ++e) {
+                        const int n = t * 16 + (ln & 15);
+                        const int kk = s * 8 + 4 * e + (ln >> 4);
+                        const int k = kperm ? (*kperm)[kk] : kk;
+                        out[(((size_t)t * kp + s) * 64 + ln) * 2 + e] = k >= 0 ? W[(size_t)n * k_in + k] : 0.0;
+                    }
         return out;
     };
     for (int i = 0; i <= NL; ++i) if (!weights[i] || !biases[i]) return fail(RANGE_ERR_INVALID, "weights[%d]/biases[%d] null", i, i);
@@ -371,7 +372,7 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     a.n_rounds = n_rounds;
     a.n_layers = NL;
     a.H = H;
-    a.ks0_total = Kp / 4;
+    a.kp0_total = Kp / 8;
     a.lds_main_doubles = lds_main;
     a.slot_base = c->d_slot_base.p;
     a.coefA = c->d_coefA.p;
