@@ -24,8 +24,8 @@
 //   grid = (query tiles) x (bank splits); a split is a contiguous range of 16-row blocks.  Because
 //   pass 2 uses GLOBAL softmax statistics its per-split partial outputs simply add, so splits
 //   give full-chip occupancy for any batch size and the same kernel serves a row-sharded bank.
-//   blockIdx is mapped so that the workgroups resident on one XCD stream the SAME split
-//   (split % 8 == blockIdx % 8): the bank rows are fetched once per XCD L2, not once per CU.
+//   blockIdx is mapped so that the workgroups resident on one XCD stream the SAME split(s)
+//   (decode_block): the bank rows are fetched once per XCD L2, not once per CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,21 +65,26 @@ struct ScanArgs {
     int64_t n_valid;       // real bank rows
     int32_t n_blocks;      // ceil(n_valid/16)
     int32_t n_qtiles;
-    int32_t n_splits;      // multiple of 8
+    int32_t n_splits;
     float k_sem;           // tau_sem * log2(e)
     float k_geo;           // tau_geo * log2(e)
     float beta;
     unsigned long long* diag;   // diagnostic build only: per (workgroup, wave) cycle sums
 };
 
-// blockIdx -> (split, query tile); blocks b and b+8 share an XCD, so each XCD gets splits
-// {xcd, xcd+8, ...} and walks each split's query tiles consecutively.
+// blockIdx -> (split, query tile).  Work items are numbered split-major (item = split * n_qtiles +
+// tile).  Blocks b and b+8 share an XCD (measured: XCC_ID == blockIdx % 8), so the blocks of XCD x
+// (b = 8j + x) take a CONTIGUOUS run of items: the workgroups resident on one XCD then stream the
+// same one or two splits and the bank rows are fetched once per XCD L2, not once per CU.
+// Bijective for any item count: XCD x owns cnt(x) = q + (x < r) items, total = 8q + r.
 __device__ __forceinline__ void decode_block(const ScanArgs& a, int& split, int& qt) {
+    const int total = a.n_splits * a.n_qtiles;
     const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    split = (idx / a.n_qtiles) * 8 + xcd;
-    qt = idx % a.n_qtiles;
+    const int x = b & 7, j = b >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int item = x * q + (x < r ? x : r) + j;
+    split = item / a.n_qtiles;
+    qt = item - split * a.n_qtiles;
 }
 
 struct QFrag {
@@ -206,6 +211,23 @@ __device__ __forceinline__ void qk_mfma(const char* kt, const KFirst& first, con
 __device__ __forceinline__ void dma_b128(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                  :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+}
+// Group form: the instruction's immediate offset is applied to BOTH the global and the LDS
+// address, so a run of pieces that is contiguous in both spaces (the 4 quarter rows of a V row,
+// the 4 rows of a K tile) needs M0 and the SGPR base only once.  dma_group_begin sets M0;
+// dma_b128_q(q) issues piece q (byte offset q*1024, q = 0..3) relative to it.  M0 must survive
+// between the statements of a group: nothing else in these kernels writes M0 (checked on the
+// generated code by tests/test_host_cpu.py::test_no_foreign_m0_writes).
+__device__ __forceinline__ void dma_group_begin(uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_b128_q(const void* sbase, uint32_t voff, int q) {
+    switch (q) {
+        case 0: asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase) : "memory"); break;
+        case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff), "s"(sbase) : "memory"); break;
+        case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(voff), "s"(sbase) : "memory"); break;
+        default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff), "s"(sbase) : "memory"); break;
+    }
 }
 __device__ __forceinline__ void dma_b32(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2"
@@ -480,11 +502,11 @@ __device__ __forceinline__ void mfma_a(f32x4& acc, float a, float b) {
 //    pieces of <= ~6 instructions (one LDS-DMA for a later tile, a slice of the next block's
 //    softmax weights) issues in the shadow of the 32-cycle MFMAs (an MFMA occupies the issue port
 //    for 8 of its 32 cycles);
-//  * the LAST step of a phase is not executed but handed on as a PvCarry (its V operands are
-//    already in registers): the next phase runs it right after its barrier, behind the first LDS
+//  * the LAST two steps of a phase are not executed but handed on as a PvCarry (their V operands are
+//    already in registers): the next phase runs them right after its barrier, behind the first LDS
 //    reads of the new phase, so no LDS latency is exposed at a phase boundary.
-struct PvCarry {
-    f32x4 v0, v1;
+struct PvCarry {          // the last PV_CARRY = 2 steps of a half (16 MFMAs = 512 cycles of cover)
+    f32x4 v0a, v1a, v0b, v1b;
     float w0, w1;
 };
 
@@ -500,18 +522,26 @@ __device__ __forceinline__ void pv_first_reads(const float* vslot, int lane, PvO
 }
 
 __device__ __forceinline__ void pv_exec_carry(f32x4 (&acc)[64], const PvCarry& c) {
-    mfma_a(acc[60], c.w0, c.v0.x);
-    mfma_a(acc[61], c.w0, c.v0.y);
-    mfma_a(acc[62], c.w0, c.v0.z);
-    mfma_a(acc[63], c.w0, c.v0.w);
-    mfma_a(acc[60], c.w1, c.v1.x);
-    mfma_a(acc[61], c.w1, c.v1.y);
-    mfma_a(acc[62], c.w1, c.v1.z);
-    mfma_a(acc[63], c.w1, c.v1.w);
+    mfma_a(acc[56], c.w0, c.v0a.x);
+    mfma_a(acc[57], c.w0, c.v0a.y);
+    mfma_a(acc[58], c.w0, c.v0a.z);
+    mfma_a(acc[59], c.w0, c.v0a.w);
+    mfma_a(acc[56], c.w1, c.v1a.x);
+    mfma_a(acc[57], c.w1, c.v1a.y);
+    mfma_a(acc[58], c.w1, c.v1a.z);
+    mfma_a(acc[59], c.w1, c.v1a.w);
+    mfma_a(acc[60], c.w0, c.v0b.x);
+    mfma_a(acc[61], c.w0, c.v0b.y);
+    mfma_a(acc[62], c.w0, c.v0b.z);
+    mfma_a(acc[63], c.w0, c.v0b.w);
+    mfma_a(acc[60], c.w1, c.v1b.x);
+    mfma_a(acc[61], c.w1, c.v1b.y);
+    mfma_a(acc[62], c.w1, c.v1b.z);
+    mfma_a(acc[63], c.w1, c.v1b.w);
 }
 
-// steps T = 0..14 of one half; (v0,v1) = operands of step 0 (already requested by the caller);
-// step 15 is returned in `carry`.  hook(h), h = 0..119, runs after MFMA h.  The sched_barriers pin
+// steps T = 0..13 of one half; s0/s1 = operands of steps 0 and 1 (already requested by the
+// caller); steps 14 and 15 are returned in `carry`.  hook(h), h = 0..111, runs after MFMA h.  The sched_barriers pin
 // each piece into its own MFMA gap: without them hipcc sinks the pieces behind groups of four
 // MFMAs, where only the last MFMA's shadow (24 issue cycles) is left to hide them.
 #define RANGE_PV_MFMA(tile, w, v, h)                 \
@@ -526,14 +556,11 @@ __device__ __forceinline__ void pv_steps(const float* vslot, float w0, float w1,
     const float* base = vslot + (2 * (lane >> 4)) * VAL_DIM + 4 * (lane & 15);
     f32x4 v0 = s0.v0, v1 = s0.v1, n0 = s1.v0, n1 = s1.v1;
 #pragma unroll
-    for (int T = 0; T < 15; ++T) {
+    for (int T = 0; T < 14; ++T) {
         // lane (j,g) reads V[row 2g+rr][64T + 4j .. +3]: one ds_read_b128 feeds 4 accumulator
         // tiles; the reads of step T+2 sit in front of step T's 8 MFMAs (512 cycles of cover)
-        f32x4 m0 = n0, m1 = n1;
-        if (T < 14) {
-            m0 = *reinterpret_cast<const f32x4*>(base + 64 * (T + 2));
-            m1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64 * (T + 2));
-        }
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(base + 64 * (T + 2));
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64 * (T + 2));
         RANGE_PV_MFMA(4 * T + 0, w0, v0.x, 8 * T + 0);
         RANGE_PV_MFMA(4 * T + 1, w0, v0.y, 8 * T + 1);
         RANGE_PV_MFMA(4 * T + 2, w0, v0.z, 8 * T + 2);
@@ -544,7 +571,7 @@ __device__ __forceinline__ void pv_steps(const float* vslot, float w0, float w1,
         RANGE_PV_MFMA(4 * T + 3, w1, v1.w, 8 * T + 7);
         v0 = n0; v1 = n1; n0 = m0; n1 = m1;
     }
-    carry.v0 = v0; carry.v1 = v1; carry.w0 = w0; carry.w1 = w1;
+    carry.v0a = v0; carry.v1a = v1; carry.v0b = n0; carry.v1b = n1; carry.w0 = w0; carry.w1 = w1;
 }
 #undef RANGE_PV_MFMA
 
@@ -618,8 +645,12 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
     // per-lane bank row of accumulator register r, relative to the block, and the number of
     // valid rows from this split's first row on (pad rows of the last block get weight 0)
     int prow[4];
+    uint32_t kvoff[4];   // per-lane source offsets of the 4 K rows this wave moves (swizzled)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
+    for (int r = 0; r < 4; ++r) {
+        prow[r] = pi_row(4 * g + r);
+        kvoff[r] = (uint32_t)((swz ^ r) << 4);
+    }
     const int n_left = (int)(a.n_valid - (int64_t)b0 * BLK);
 
     // Schedule (per wave; "half" = 8 bank rows, two per 16-row block t):
@@ -654,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
     }
     int vs = 0;   // V slot of half 2t
     PvCarry carry;
-    carry.v0 = carry.v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    carry.v0a = carry.v1a = carry.v0b = carry.v1b = f32x4{0.f, 0.f, 0.f, 0.f};
     carry.w0 = carry.w1 = 0.f;
     unsigned long long d_vm0 = 0, d_bar0 = 0, d_pv0 = 0, d_vm1 = 0, d_bar1 = 0, d_qk = 0, d_pv1 = 0;
     unsigned long long d_mark = 0;
@@ -682,9 +713,10 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
             pv_exec_carry(acc, carry);                       // last step of the previous half
             pv_steps(vring + vs * 8 * VAL_DIM, w_cur[0], w_cur[1], s0, s1, acc, lane, carry,
                      [&](int h) __attribute__((always_inline)) {
-                         if ((h & 15) == 3) {                // 8 pieces: V half 2t+2
-                             const int ii = h >> 4;
-                             dma_b128(vsrc1 + ii * 256, vvoff, vdst_e + ii * 1024);
+                         if (h % 14 == 3) {                  // 8 pieces: V half 2t+2
+                             const int ii = h / 14;
+                             if ((ii & 3) == 0) dma_group_begin(vdst_e + (ii >> 2) * 4096);
+                             dma_b128_q(vsrc1 + (ii >> 2) * VAL_DIM, vvoff, ii & 3);
                          }
                      });
         }
@@ -710,10 +742,15 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
                 [&](int h) __attribute__((always_inline)) {
                     if ((h & 7) == 3) {
                         const int ii = h >> 3;               // 13 pieces: V half 2t+3, K/X tile t+2
-                        if (ii < 8) dma_b128(vsrc1 + 8 * VAL_DIM + ii * 256, vvoff, vdst_o + ii * 1024);
-                        else if (ii < 12) dma_b128(ksrc2 + (ii - 8) * KEY_DIM, (uint32_t)((swz ^ (ii - 8)) << 4),
-                                                   kdst + (ii - 8) * 1024);
-                        else if (ii == 12) dma_b32(xsrc2, (uint32_t)(lane << 2), xdst);
+                        if (ii < 8) {
+                            if ((ii & 3) == 0) dma_group_begin(vdst_o + (ii >> 2) * 4096);
+                            dma_b128_q(vsrc1 + (8 + (ii >> 2)) * VAL_DIM, vvoff, ii & 3);
+                        } else if (ii < 12) {
+                            if (ii == 8) dma_group_begin(kdst);
+                            dma_b128_q(ksrc2, kvoff[ii - 8], ii - 8);
+                        } else if (ii == 12) {
+                            dma_b32(xsrc2, (uint32_t)(lane << 2), xdst);
+                        }
                     } else if (h >= 21 && h < 101 && ((h - 21) & 3) == 0) {
                         // weights of block t+1 in 20 slices of <= 4 VALU instructions; the first
                         // runs >= 20 MFMAs after the last QK MFMA, whose results are long readable

@@ -134,22 +134,23 @@ struct DeviceGuard {
     }
 };
 
-// Number of bank splits (multiple of 8, one family of splits per XCD).  Workgroups of both scan
-// kernels are equal-cost, so the chip runs them in near lock-step "rounds" of n_cu * wg_per_cu
-// workgroups: pick the split count whose last round is best filled, preferring fewer splits
-// (less partial-result traffic) on ties.  wg_per_cu: 1 for pass 2 (512 registers, 129 KB LDS),
-// 3 for pass 1 (49 KB LDS).
+// Number of bank splits.  Workgroups of both scan kernels are equal-cost, so the chip runs them
+// in near lock-step "rounds" of n_cu * wg_per_cu workgroups: pick the split count whose last
+// round is best filled (e.g. 157 query tiles x 13 splits = 2041 workgroups = 7.97 rounds of 256),
+// preferring fewer splits (less partial-result traffic) on near-ties.  wg_per_cu: 1 for pass 2
+// (512 registers, 129 KB LDS), 3 for pass 1 (49 KB LDS).
 int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits) {
     const double slots = (double)n_cu * wg_per_cu;
-    int best = 8;
-    double best_eff = -1.0;
-    for (int ns = 8; ns <= max_splits; ns += 8) {
-        if (ns > 8 && (int64_t)ns * 4 > n_blocks) break;   // keep >= 4 blocks per split
+    int best = 1;
+    double best_score = -1.0;
+    for (int ns = 1; ns <= max_splits; ++ns) {
+        if (ns > 1 && (int64_t)ns * 4 > n_blocks) break;   // keep >= 4 blocks per split
         const double total = (double)n_qtiles * ns;
         const double rounds = std::ceil(total / slots);
-        double eff = total / (rounds * slots);
-        if (rounds < 4) eff *= 0.9;                         // prefer a few rounds: smoother tail
-        if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
+        double score = total / (rounds * slots);            // fill of the rounds
+        if (rounds < 4) score *= 0.85 + 0.0375 * rounds;    // few rounds: ragged finish hurts more
+        score -= 0.002 * ns;                                // partial-result traffic
+        if (score > best_score) { best_score = score; best = ns; }
     }
     return best;
 }
@@ -206,7 +207,7 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
     // pass 1 writes 16 B per (query, split): many splits are free; pass 2 writes a 4 KB row
     a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 3, p1_max_splits)
-                       : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1, 64);
+                       : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1, 32);
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
     a.beta = 1.f;

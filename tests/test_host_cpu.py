@@ -89,3 +89,34 @@ def test_engine_requires_gpu():
         _native.HipEngine("cuda:0")
     with pytest.raises(_native.RangeNativeError):
         _native.HipEngine("cpu")
+
+
+def test_no_foreign_m0_writes(tmp_path):
+    """The LDS-DMA groups in attend_kernels.h set M0 in one asm statement and rely on it in the
+    next three (include comment at dma_group_begin).  That is only sound while hipcc itself never
+    writes M0 in those kernels: check the generated gfx950 assembly."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / "dev.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                    "-o", str(out), os.path.join(REPO, "range_amd", "csrc", "range_hip.hip")],
+                   check=True, cwd=REPO, capture_output=True)
+    text = out.read_text()
+    kernels = re.split(r"\n(?=_ZN9range_hip\w+:)", text)
+    checked = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if "attend_kernel" not in name and "scan_stats_kernel" not in name:
+            continue
+        checked += 1
+        in_asm = False
+        for line in k.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and re.search(r"\bm0\b", line.split(";")[0]):
+                raise AssertionError(f"{name}: compiler-generated M0 access: {line.strip()}")
+    assert checked >= 6
