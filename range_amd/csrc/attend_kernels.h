@@ -131,6 +131,14 @@ __device__ __forceinline__ void pin_qfrag(QFrag& f) {
 // the ds_read_b128 below bank-conflict free.  The k index is consumed in a permuted order that is
 // identical for both operands.  Two accumulation chains hide the 40-cycle dependent-MFMA latency;
 // the SAME summation order is used in both passes so pass 2 reproduces pass 1's logits bit for bit.
+// single-instruction f32 add (keeps hipcc from SLP-packing the logit sums into v_pk_add_f32 plus
+// the v_mov shuffles that feed it)
+__device__ __forceinline__ float add1(float x, float y) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // Accumulators of one transposed logit tile: four independent semantic chains (one per element of
 // the 16-byte K read; a VGPR-accumulator MFMA chain needs ~3 MFMAs of distance to issue back to
 // back) and the geographic tile.  sem(r) is the fixed summation order used by BOTH passes.
@@ -281,7 +289,7 @@ __device__ __forceinline__ void issue_v_half(const float* values, int64_t row0, 
 
 // wait for all but the n youngest vector-memory operations of this wave, then workgroup barrier.
 // One asm statement with a memory clobber: no LDS access may be moved across it by the compiler.
-#define RANGE_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+#define RANGE_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Diagnostic build only (attend_kernel<GEO, true>, never on the product path): s_memtime stamps
 // around the two parts of a wait so that their cycles can be summed per wave.
@@ -293,7 +301,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define RANGE_WAIT_BARRIER_DIAG(n, vm, bar)                                   \
     do {                                                                      \
         const unsigned long long t0_ = stamp();                               \
-        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");                 \
+        asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory");      \
         const unsigned long long t1_ = stamp();                               \
         asm volatile("s_barrier" ::: "memory");                               \
         const unsigned long long t2_ = stamp();                               \
@@ -339,9 +347,9 @@ struct TopK {
 template <bool GEO, bool TOPK>
 __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: K ring 3 x [16][256] f32 | X ring 3 x [16][4] f32
+    // LDS: K ring 2 x [16][256] f32 | X ring 2 x [16][4] f32 (33 KB: four workgroups per CU)
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
-    const uint32_t kring_lds = lds0, xring_lds = lds0 + 3 * BLK * KEY_DIM * 4;
+    const uint32_t kring_lds = lds0, xring_lds = lds0 + 2 * BLK * KEY_DIM * 4;
     constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
 
     const int lane = threadIdx.x & 63;
@@ -365,26 +373,22 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     TopK<TOPK ? MAX_TOPK : 1> tk;
     if (TOPK) tk.init();
 
-    // ring of 3 K tiles, prefetch distance 2; 5 LDS-DMA operations per wave and tile.
+    // ring of 2 K tiles: tile t+1 is requested right after barrier t (every wave is then done
+    // with tile t-1, whose slot it re-uses) and waited for before barrier t+1.
     if (nb > 0) {
         issue_k_tile(a.keys, a.xyz4, (int64_t)b0 * BLK, kring_lds, xring_lds, wave, lane, swz);
-        if (nb > 1)
-            issue_k_tile(a.keys, a.xyz4, (int64_t)(b0 + 1) * BLK, kring_lds + KT_BYTES,
-                         xring_lds + 256, wave, lane, swz);
     }
     int slot = 0;
     for (int t = 0; t < nb; ++t) {
-        // tile t landed (mine: counted wait; everyone's: barrier).  The barrier also says every
-        // wave is done with tile t-1, whose slot tile t+2 re-uses.
-        if (t + 1 < nb) RANGE_WAIT_BARRIER(5); else RANGE_WAIT_BARRIER(0);
-        if (t + 2 < nb) {
-            const int s2 = slot >= 1 ? slot - 1 : 2;   // (slot + 2) % 3
-            issue_k_tile(a.keys, a.xyz4, (int64_t)(b0 + t + 2) * BLK, kring_lds + s2 * KT_BYTES,
+        RANGE_WAIT_BARRIER(0);
+        if (t + 1 < nb) {
+            const int s2 = slot ^ 1;
+            issue_k_tile(a.keys, a.xyz4, (int64_t)(b0 + t + 1) * BLK, kring_lds + s2 * KT_BYTES,
                          xring_lds + s2 * 256, wave, lane, swz);
         }
         QKAcc c;
         qk_mfma<GEO>(smem + slot * KT_BYTES,
-                     qk_first_reads<GEO>(smem + slot * KT_BYTES, smem + 3 * KT_BYTES + slot * 256, kaddr),
+                     qk_first_reads<GEO>(smem + slot * KT_BYTES, smem + 2 * KT_BYTES + slot * 256, kaddr),
                      kaddr, f, c, [](int) __attribute__((always_inline)) {});
         c.fence();
         const f32x4 ss = {c.sem(0), c.sem(1), c.sem(2), c.sem(3)};
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t2[r] - mn) : 0.f;
             l2 = acc; m2 = mn;
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        slot ^= 1;
     }
     // lanes j, j+16, j+32, j+48 hold disjoint row subsets of the same query
 #pragma unroll
@@ -575,14 +579,6 @@ __device__ __forceinline__ void pv_steps(const float* vslot, float w0, float w1,
 }
 #undef RANGE_PV_MFMA
 
-// single-instruction f32 add (keeps hipcc from SLP-packing the logit sums into v_pk_add_f32 plus
-// the v_mov shuffles that feed it)
-__device__ __forceinline__ float add1(float x, float y) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-
 // MFMA results -> any non-MFMA reader: wait states first (hipcc pads nothing after an asm MFMA).
 __device__ __forceinline__ void acc_fence(f32x4 (&acc)[64]) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
@@ -596,7 +592,7 @@ __device__ __forceinline__ void acc_fence(f32x4 (&acc)[64]) {
 
 // LDS map (bytes): V ring 3 x 32 KB | K ring 2 x 16 KB | X ring 2 x 256 B  = 131,584 B
 constexpr int ATTEND_LDS_BYTES = (3 * 8 * VAL_DIM + 2 * BLK * KEY_DIM + 2 * 64) * 4;
-constexpr int SCAN_LDS_BYTES = (3 * BLK * KEY_DIM + 3 * 64) * 4;
+constexpr int SCAN_LDS_BYTES = (2 * BLK * KEY_DIM + 2 * 64) * 4;
 
 template <bool GEO, bool DIAG = false>
 __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {

@@ -138,7 +138,7 @@ struct DeviceGuard {
 // in near lock-step "rounds" of n_cu * wg_per_cu workgroups: pick the split count whose last
 // round is best filled (e.g. 157 query tiles x 13 splits = 2041 workgroups = 7.97 rounds of 256),
 // preferring fewer splits (less partial-result traffic) on near-ties.  wg_per_cu: 1 for pass 2
-// (512 registers, 129 KB LDS), 3 for pass 1 (49 KB LDS).
+// (512 registers, 129 KB LDS), 4 for pass 1 (33 KB LDS, <= 128 VGPRs).
 int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits) {
     const double slots = (double)n_cu * wg_per_cu;
     int best = 1;
@@ -206,7 +206,7 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.n_blocks = (int32_t)((c->n_rows + BLK - 1) / BLK);
     a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
     // pass 1 writes 16 B per (query, split): many splits are free; pass 2 writes a 4 KB row
-    a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 3, p1_max_splits)
+    a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 4, p1_max_splits)
                        : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1, 32);
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
