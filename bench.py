@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--bank", default="range_db_large", choices=sorted(synth.BANK_ROWS))
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--beta", type=float, default=0.5)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the row-sharded (torch.distributed) path even with one rank "
+                         "(rehearsal of the N>1 code path on a 1-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=2048,
                     help="queries of the same workload timed on the host for cpu_baseline (0=off)")
     return ap.parse_args()
@@ -93,7 +96,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    sharded = world > 1 or a.force_sharded
+    if sharded:
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, shard_rows
         init_from_env("nccl")
@@ -105,7 +109,7 @@ def main():
     bank = prepare_bank(*bank_arrays)
     eng = _native.HipEngine(dev)
     eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
-    if world == 1:
+    if not sharded:
         eng.set_bank(bank.keys, bank.values, bank.xyz, 0)
         n_local = N
     else:
@@ -120,14 +124,14 @@ def main():
     out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
 
     def step():
-        if world == 1:
+        if not sharded:
             eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
         else:
             out.copy_(model(x))
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -140,7 +144,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -148,11 +152,12 @@ def main():
     st_ms, st_n = eng.profile_read(1)
     en_ms, en_n = eng.profile_read(0)
     eng.profile_enable(False)
-    assert att_n == a.steps, (att_n, a.steps)
+    assert att_n >= a.steps and att_n % a.steps == 0, (att_n, a.steps)   # sharded: one per chunk
     assert bool(torch.isfinite(out).all())
 
     if rank == 0:
-        q_per_launch = B * world                      # every rank attends all queries
+        launches_per_step = att_n // a.steps
+        q_per_launch = B * world // launches_per_step  # every rank attends all queries (in chunks)
         att_avg_ms = att_ms / att_n
         flops = q_per_launch * n_local * FLOP_PAIR_ATTEND
         achieved = flops / (att_avg_ms * 1e-3) / 1e12
@@ -177,7 +182,7 @@ def main():
                                    f"weights), {a.bank} (synthetic, N={N}), {B} queries per GPU "
                                    "per step, device-resident in/out",
                        "bank_rows": N, "queries_per_gpu": B, "hidden": H,
-                       "bank_layout": "single GPU" if world == 1 else f"row-sharded x{world}",
+                       "bank_layout": "single GPU" if not sharded else f"row-sharded x{world}",
                        "query_tiles": qt, "bank_splits": ns},
             "roofline": {"kernel": "attend_kernel<GEO> (pass 2: logits + w@V, f32 MFMA)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
@@ -187,14 +192,14 @@ def main():
                          "flop_per_launch": flops,
                          "algorithmic_bytes_per_launch": n_local * BANK_ROW_BYTES
                                                          + q_per_launch * (1040 + 4096)},
-            "kernels_ms_per_step": {"encoder": en_ms / max(en_n, 1), "scan_stats": st_ms / max(st_n, 1),
-                                    "attend": att_avg_ms},
+            "kernels_ms_per_step": {"encoder": en_ms / a.steps, "scan_stats": st_ms / a.steps,
+                                    "attend": att_ms / a.steps},
             "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / (dt / a.steps) / 1e12,
         }
         if world == 1 and a.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
         print(json.dumps(res))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,6 +15,9 @@ decomposes exactly over row shards:
        peer, so all 7 xGMI links of a GPU carry 1/7 of the traffic each - not a ring)
     7. finalize: fixed-order sum of the W slices + pack with e64 -> (B,1280) float64
 
+Steps 5-7 run per query chunk: the all-to-all of chunk c is asynchronous (RCCL's own stream) and
+overlaps pass 2 of chunk c+1, so only the last chunk's exchange is exposed.
+
 The top-k side channel merges per-shard candidate lists with ONE all-gather (north star).
 
 Per-GPU work is B_total * N / W = B * N: adding GPUs adds queries at constant time per step
@@ -39,8 +42,11 @@ def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 class ShardedRange:
     """RANGE / RANGE+ forward over a row-sharded bank.  ``engine`` holds THIS rank's rows."""
 
+    #: queries per rank and chunk below which a forward is not split further
+    min_chunk = 2048
+
     def __init__(self, engine, model_name: str = "RANGE+", beta: Optional[float] = 0.5,
-                 group=None):
+                 group=None, n_chunks: Optional[int] = None):
         if model_name == "RANGE":
             self.tau_sem, self.tau_geo, self.beta = TEMP_RANGE, 0.0, 1.0
         elif model_name == "RANGE+":
@@ -51,6 +57,7 @@ class ShardedRange:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.n_chunks = n_chunks   # None: 4 chunks when there is a peer to exchange with
 
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         # concatenation form (W*n, ...): accepted by both the RCCL and the gloo backend
@@ -74,10 +81,35 @@ class ShardedRange:
         e64, e32_all, xq_all = self._gather_queries(lonlat)
         stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo)
         stats = self.engine.merge_stats(self._gather(stats_local))
-        partial = self.engine.attend(e32_all, xq_all, self.tau_sem, self.tau_geo, self.beta, stats)
-        mine = torch.empty_like(partial)
-        dist.all_to_all_single(mine, partial, group=self.group)     # (W, B, 1024) slices
-        return self.engine.finalize(mine.reshape(W, B, partial.shape[1]), e64)
+        n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
+        n_chunks = max(1, min(n_chunks, B // self.min_chunk if B >= self.min_chunk else 1))
+        if n_chunks == 1:
+            partial = self.engine.attend(e32_all, xq_all, self.tau_sem, self.tau_geo, self.beta, stats)
+            mine = torch.empty_like(partial)
+            dist.all_to_all_single(mine, partial, group=self.group)     # (W, B, 1024) slices
+            return self.engine.finalize(mine.reshape(W, B, partial.shape[1]), e64)
+        # chunked: rows [lo,hi) of EVERY rank's queries form one chunk, ordered by owner rank, so
+        # that the chunk's partial is again W equal slices, one per destination
+        e32_v = e32_all.reshape(W, B, -1)
+        xq_v = xq_all.reshape(W, B, -1)
+        st_v = stats.reshape(W, B, -1)
+        bounds = [(B * c) // n_chunks for c in range(n_chunks + 1)]
+        pending = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            n = hi - lo
+            part = self.engine.attend(e32_v[:, lo:hi].reshape(W * n, -1).contiguous(),
+                                      xq_v[:, lo:hi].reshape(W * n, -1).contiguous(),
+                                      self.tau_sem, self.tau_geo, self.beta,
+                                      st_v[:, lo:hi].reshape(W * n, -1).contiguous())
+            recv = torch.empty_like(part)
+            work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
+            pending.append((work, recv, part, lo, hi))
+        outs = []
+        for work, recv, part, lo, hi in pending:
+            work.wait()
+            outs.append(self.engine.finalize(recv.reshape(W, hi - lo, recv.shape[1]),
+                                             e64[lo:hi].contiguous()))
+        return torch.cat(outs, dim=0)
 
     __call__ = forward
 

@@ -104,8 +104,9 @@ def _worker(rank, world, port, N, B, L, H, ret):
         shard = O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1])
         w = synth.make_encoder_weights(L, H, 256, 2, 5)
         q = synth.make_queries(B, seed=100 + rank)
-        for name, beta in (("RANGE+", 0.5), ("RANGE+", 0.0), ("RANGE", None)):
-            model = ShardedRange(OracleShardEngine(w, L, shard, r0), name, beta)
+        for name, beta, chunks in (("RANGE+", 0.5, 1), ("RANGE+", 0.0, 3), ("RANGE", None, 2)):
+            model = ShardedRange(OracleShardEngine(w, L, shard, r0), name, beta, n_chunks=chunks)
+            model.min_chunk = 2          # exercise the chunked, overlapped exchange on tiny batches
             out = model(torch.from_numpy(q)).numpy()
             ref = O.forward(q, w, L, full, name, beta)      # unsharded oracle, own queries
             err = float(np.abs(out - ref).max())

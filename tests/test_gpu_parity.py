@@ -323,13 +323,15 @@ def test_sharded_path_over_rccl_world1(tmp_path):
         bank, obank, w, enc, q, e = _synthetic_case(N, B)
         eng = _engine(enc, bank)
         x = _dev(q)
-        for name, beta in (("RANGE+", 0.5), ("RANGE", None)):
-            out = ShardedRange(eng, name, beta)(x).cpu().numpy()
+        for name, beta, chunks in (("RANGE+", 0.5, 1), ("RANGE", None, 1), ("RANGE+", 0.5, 3)):
+            model = ShardedRange(eng, name, beta, n_chunks=chunks)
+            model.min_chunk = 16                      # chunked + asynchronous exchange
+            out = model(x).cpu().numpy()
             ref = O.forward(q, w, 10, obank, name, beta)
             np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
             single = eng.forward(x, _native.MODEL_RANGE_PLUS if name == "RANGE+" else _native.MODEL_RANGE,
                                  1.0 if beta is None else beta).cpu().numpy()
-            np.testing.assert_allclose(out, single, rtol=0, atol=0)
+            np.testing.assert_allclose(out, single, rtol=0, atol=0 if chunks == 1 else 2e-6)
         tv, ti = ShardedRange(eng, "RANGE+", 0.5).topk(x, 8)
         s, _ = O.logits64(e, q, obank)
         _topk_ok(ti.cpu().numpy(), tv.cpu().numpy(), s, 8)
