@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded (torch.distributed) path even with one rank "
                          "(rehearsal of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--shard-chunks", type=int, default=0,
+                    help="query chunks of the sharded forward (0 = library default: 4 when N>1)")
     ap.add_argument("--cpu-sample", type=int, default=2048,
                     help="queries of the same workload timed on the host for cpu_baseline (0=off)")
     return ap.parse_args()
@@ -117,7 +119,7 @@ def main():
         sh = bank.rows(r0, r1)
         eng.set_bank(sh.keys, sh.values, sh.xyz, r0)
         n_local = r1 - r0
-        model = ShardedRange(eng, "RANGE+", a.beta)
+        model = ShardedRange(eng, "RANGE+", a.beta, n_chunks=a.shard_chunks or None)
 
     B = a.queries
     x = torch.from_numpy(synth.make_queries(B, seed=7 + rank)).to(dev)
@@ -163,7 +165,7 @@ def main():
         achieved = flops / (att_avg_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(REPO, "profiles", "attend_pmc.json")
-        if world == 1 and os.path.exists(pmc):
+        if not sharded and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:

@@ -103,6 +103,7 @@ class LocationEncoder(nn.Module):
         B = x.shape[0]
         beta = 1.0 if self._model_id == _native.MODEL_RANGE else float(self.args.beta)
         out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
+        # (B == 0: nothing to launch; the reference returns an empty (0,1280) array as well)
         for i in range(0, B, self.chunk_size):
             self.engine.forward(x[i:i + self.chunk_size], self._model_id, beta,
                                 out=out[i:i + self.chunk_size])

@@ -1,0 +1,99 @@
+"""Batch driver: ``save_embeddings`` - the only real caller of ``model(coords)`` in the reference
+(range/utils/save.py:7-58; CLI at range/range.py:281-298) - with the device->host copy of the
+(B,1280) float64 result taken off the critical path.
+
+The reference does, per batch: H2D of coords, forward, a synchronous D2H of 10 KB per query
+(``.cpu()`` at range.py:240), numpy bookkeeping.  Here the batches flow through a two-deep
+pipeline: the engine computes batch i on torch's current stream while a copy stream drains batch
+i-1 into pinned memory and the host scatters batch i-2 into the final array.  Same signature,
+same output files (``np.savez(path, coords=, embeddings=, y=)``), same directory layout.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+class EmbeddingPipeline:
+    """Streams batches of (lon,lat) coordinates through a range_amd ``LocationEncoder`` and
+    yields host ``numpy`` arrays in order, overlapping compute, D2H and host copies."""
+
+    def __init__(self, model, depth: int = 2):
+        self.model = model
+        self.engine = model.engine
+        self.device = self.engine.device
+        self.depth = max(2, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._pinned: List[Optional[torch.Tensor]] = [None] * self.depth
+        self._dev: List[Optional[torch.Tensor]] = [None] * self.depth
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]
+        self._copied = [torch.cuda.Event() for _ in range(self.depth)]
+
+    def _buffers(self, slot: int, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        dim = self.model.location_feature_dim
+        if self._pinned[slot] is None or self._pinned[slot].shape[0] < n:
+            self._pinned[slot] = torch.empty((n, dim), dtype=torch.float64).pin_memory()
+            self._dev[slot] = torch.empty((n, dim), dtype=torch.float64, device=self.device)
+        return self._pinned[slot][:n], self._dev[slot][:n]
+
+    @torch.no_grad()
+    def run(self, batches: Iterable) -> Iterator[np.ndarray]:
+        """``batches`` yields (B,2) coordinate tensors/arrays.  Yields one float64 ndarray
+        (B,1280) per batch, in order.  Each yielded array is a fresh host array."""
+        inflight: List[Tuple[int, int]] = []          # (slot, rows)
+        compute = torch.cuda.current_stream(self.device)
+        i = 0
+        for coords in batches:
+            slot = i % self.depth
+            if len(inflight) == self.depth:           # slot about to be reused: drain it first
+                yield self._collect(*inflight.pop(0))
+            x = self.model._coords(coords)
+            n = x.shape[0]
+            pinned, dev = self._buffers(slot, n)
+            beta = 1.0 if self.model._model_id == 0 else float(self.model.args.beta)
+            for lo in range(0, n, self.model.chunk_size):
+                self.engine.forward(x[lo:lo + self.model.chunk_size], self.model._model_id, beta,
+                                    out=dev[lo:lo + self.model.chunk_size])
+            self._done[slot].record(compute)
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self._done[slot])
+                pinned.copy_(dev, non_blocking=True)
+                self._copied[slot].record(self.copy_stream)
+            inflight.append((slot, n))
+            i += 1
+        while inflight:
+            yield self._collect(*inflight.pop(0))
+
+    def _collect(self, slot: int, n: int) -> np.ndarray:
+        self._copied[slot].synchronize()
+        return self._pinned[slot][:n].numpy().copy()
+
+
+def save_embeddings(args, train_loader, val_loader, location_model):
+    """Drop-in for range/utils/save.py:7-58."""
+    embeddings_dir = os.path.join(args.embeddings_dir, args.location_model_name)
+    if not os.path.exists(embeddings_dir):
+        print(f"Creating new directory {embeddings_dir}")
+        os.makedirs(embeddings_dir)
+    train_path = os.path.join(embeddings_dir, f"{args.task_name}_train.npz")
+    val_path = os.path.join(embeddings_dir, f"{args.task_name}_val.npz")
+    location_model.eval()
+    pipe = EmbeddingPipeline(location_model)
+    for loader, path in ((train_loader, train_path), (val_loader, val_path)):
+        coords_list, y_list = [], []
+
+        def coords_iter():
+            for coords, y in loader:
+                coords_list.append(coords.cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords))
+                y_list.append(y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y))
+                yield coords
+
+        embeddings_list = list(pipe.run(coords_iter()))
+        np.savez(path, coords=np.concatenate(coords_list, axis=0),
+                 embeddings=np.concatenate(embeddings_list, axis=0),
+                 y=np.concatenate(y_list, axis=0))
+        print(f"File saved to {path}")
+    print(f"File saved to {train_path} and {val_path}")

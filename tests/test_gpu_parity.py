@@ -337,3 +337,31 @@ def test_sharded_path_over_rccl_world1(tmp_path):
         _topk_ok(ti.cpu().numpy(), tv.cpu().numpy(), s, 8)
     finally:
         dist.destroy_process_group()
+
+
+def test_save_embeddings_driver(tmp_path):
+    """range_amd.save.save_embeddings (reference: utils/save.py:7-58): same files, same arrays as
+    calling the model batch by batch; ragged last batch; pipelined D2H."""
+    from argparse import Namespace
+    from range_amd import load_model
+    from range_amd.save import EmbeddingPipeline, save_embeddings
+    ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 900, 3)
+    m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=0.25)
+    q = synth.make_queries(1000, seed=31)
+    y = np.arange(1000)
+    def loader(a, b, bs):
+        return [(torch.from_numpy(q[i:min(i + bs, b)]), torch.from_numpy(y[i:min(i + bs, b)]))
+                for i in range(a, b, bs)]
+    args = Namespace(embeddings_dir=str(tmp_path / "emb"), location_model_name="RANGE+",
+                     task_name="unit", device="cuda:0")
+    save_embeddings(args, loader(0, 700, 128), loader(700, 1000, 77), m)
+    ref = m(torch.from_numpy(q))
+    tr = np.load(tmp_path / "emb" / "RANGE+" / "unit_train.npz")
+    va = np.load(tmp_path / "emb" / "RANGE+" / "unit_val.npz")
+    assert np.array_equal(tr["coords"], q[:700]) and np.array_equal(va["y"], y[700:])
+    np.testing.assert_allclose(tr["embeddings"], ref[:700], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(va["embeddings"], ref[700:], rtol=0, atol=2e-6)
+    outs = list(EmbeddingPipeline(m, depth=3).run([q[:10], q[10:11], q[11:500]]))
+    assert [o.shape[0] for o in outs] == [10, 1, 489]
+    np.testing.assert_allclose(np.concatenate(outs), ref[:500], rtol=0, atol=2e-6)
