@@ -92,6 +92,11 @@ int64_t range_bank_rows(const range_ctx* ctx);
 int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* ehat64_dev,
                  float* ehat32_dev, float* xq32_dev, range_stream_t stream);
 
+/* Kernel A, plain SatCLIP output: the un-normalised (B,256) float64 embedding that
+ * LocationEncoder.forward returns for model_name == 'SatCLIP' (range/range.py:244-245). */
+int range_encode_raw(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* eraw64_dev,
+                     range_stream_t stream);
+
 /* Kernel B, pass 1.  Streaming log-sum-exp statistics of the temperature-scaled logits of
  * range/range.py:213-215 (semantic) and :231-234 (geographic) over THIS ctx's bank rows.
  *   tau_sem, tau_geo : temperatures (range.py:103, 108-109); tau_geo <= 0 disables the geo head
@@ -123,6 +128,12 @@ int range_merge_topk(range_ctx* ctx, const float* val_parts_dev, const int64_t* 
 int range_attend(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
                  float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
                  float* partial_dev, range_stream_t stream);
+
+/* The blend of range/range.py:238 on its own, with the reference's float32 rounding:
+ * out = (1-beta)*G + beta*H over (B,1024) float32.  For beta sweeps: G = range_attend(beta=0),
+ * H = range_attend(beta=1) once, then one blend + finalize per beta. */
+int range_blend(range_ctx* ctx, const float* G_dev, const float* H_dev, float beta, int64_t B,
+                float* out_dev, range_stream_t stream);
 
 /* Replaces the pack of range/range.py:222 / :240: out (B,1280) float64 =
  * [ sum over parts of partials (n_parts,B,1024) f32 widened | ehat64 (B,256) ]. */

@@ -27,7 +27,7 @@ SYMBOLS = (
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
-    "range_attend_diag",
+    "range_attend_diag", "range_encode_raw", "range_blend",
 )
 
 
@@ -75,6 +75,8 @@ def load_library() -> C.CDLL:
     lib.range_profile_enable.argtypes = [vp, i32]
     lib.range_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i32)]
     lib.range_attend_diag.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, i64, vp]
+    lib.range_encode_raw.argtypes = [vp, vp, i64, vp, vp]
+    lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
     if lib.range_abi_version() != 1:
@@ -180,6 +182,24 @@ class HipEngine:
         _check(self.lib, self.lib.range_encode(self._h, lonlat.data_ptr(), B, e64.data_ptr(),
                                                e32.data_ptr(), xq.data_ptr(), self._stream()))
         return e64, e32, xq
+
+    def encode_raw(self, lonlat: torch.Tensor) -> torch.Tensor:
+        """Un-normalised SatCLIP embedding (B,256) float64 (range.py:244-245)."""
+        self._t(lonlat, torch.float64, (2,))
+        B = lonlat.shape[0]
+        out = self._empty((B, KEY_DIM), torch.float64)
+        _check(self.lib, self.lib.range_encode_raw(self._h, lonlat.data_ptr(), B, out.data_ptr(),
+                                                   self._stream()))
+        return out
+
+    def blend(self, G: torch.Tensor, H: torch.Tensor, beta: float) -> torch.Tensor:
+        """(1-beta)*G + beta*H with the reference's float32 rounding (range.py:238)."""
+        self._t(G, torch.float32, (VAL_DIM,))
+        self._t(H, torch.float32, (VAL_DIM,))
+        out = self._empty(tuple(G.shape), torch.float32)
+        _check(self.lib, self.lib.range_blend(self._h, G.data_ptr(), H.data_ptr(), beta,
+                                              G.shape[0], out.data_ptr(), self._stream()))
+        return out
 
     def scan_stats(self, e32: torch.Tensor, xq: torch.Tensor, tau_sem: float, tau_geo: float,
                    topk: int = 0):

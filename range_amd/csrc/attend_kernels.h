@@ -810,6 +810,21 @@ __global__ void reduce_parts_kernel(const float* parts, int n_parts, int64_t tot
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
+// out = (1-beta)*G + beta*H, elementwise f32, with the reference's rounding (two products, one
+// sum, no FMA contraction): range/range.py:238.  Used by the beta sweep, where H (beta=1) and G
+// (beta=0) are computed once and blended for every beta.
+__global__ void blend_kernel(const float* G, const float* H, float beta, int64_t n4, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = reinterpret_cast<const f32x4*>(G)[i];
+    const f32x4 h = reinterpret_cast<const f32x4*>(H)[i];
+    const float a = 1.0f - beta;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(a, g[k]), __fmul_rn(beta, h[k]));
+    reinterpret_cast<f32x4*>(out)[i] = o;
+}
+
 // out (B,1280) f64 = [ sum_p partial_p (f32, widened) | ehat64 ]      (range/range.py:222, :240)
 __global__ void finalize_kernel(const float* parts, int n_parts, const double* ehat64, int64_t B,
                                 double* out) {

@@ -36,7 +36,8 @@ constexpr int ENC_EMBED = 256;
 
 struct EncArgs {
     const double* lonlat;   // (B,2)
-    double* ehat64;         // (B,256)
+    double* ehat64;         // (B,256) normalised
+    double* eraw64;         // (B,256) un-normalised SirenNet output, or null
     float* ehat32;          // (B,256)
     float* xq;              // (B,4)
     int64_t B;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int n = (wave * 4 + i) * 16 + (lane & 15);
                     const double e = ae[qt][i][r] / nrm;
+                    if (a.eraw64) a.eraw64[q * ENC_EMBED + n] = ae[qt][i][r];
                     a.ehat64[q * ENC_EMBED + n] = e;
                     a.ehat32[q * ENC_EMBED + n] = (float)e;
                 }

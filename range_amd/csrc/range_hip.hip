@@ -412,8 +412,8 @@ int range_set_bank(range_ctx* c, const float* keys, const float* values, const f
     return RANGE_OK;
 }
 
-int range_encode(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
-                 float* xq32, range_stream_t stream) {
+static int encode_impl(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
+                       float* xq32, double* eraw64, range_stream_t stream) {
     if (!c || !lonlat || !ehat64 || !ehat32 || !xq32) return fail(RANGE_ERR_INVALID, "null argument");
     if (!c->has_encoder) return fail(RANGE_ERR_STATE, "encoder not set (range_set_encoder)");
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
@@ -422,10 +422,41 @@ int range_encode(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, 
     EncArgs a = c->enc;
     a.lonlat = lonlat;
     a.ehat64 = ehat64;
+    a.eraw64 = eraw64;
     a.ehat32 = ehat32;
     a.xq = xq32;
     a.B = B;
     return launch_encoder(c, a, (hipStream_t)stream);
+}
+
+int range_encode(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
+                 float* xq32, range_stream_t stream) {
+    return encode_impl(c, lonlat, B, ehat64, ehat32, xq32, nullptr, stream);
+}
+
+int range_encode_raw(range_ctx* c, const double* lonlat, int64_t B, double* eraw64,
+                     range_stream_t stream) {
+    if (!c || !eraw64) return fail(RANGE_ERR_INVALID, "null argument");
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    {
+        DeviceGuard g(c->device);
+        HIP_TRY(c->ws_ehat64.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
+    }
+    return encode_impl(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, eraw64, stream);
+}
+
+int range_blend(range_ctx* c, const float* G, const float* H, float beta, int64_t B, float* out,
+                range_stream_t stream) {
+    if (!c || !G || !H || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    DeviceGuard g(c->device);
+    const int64_t n4 = B * (VAL_DIM / 4);
+    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, G, H, beta, n4, out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
 }
 
 int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,

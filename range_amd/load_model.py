@@ -8,10 +8,10 @@ from .range import LocationEncoder
 
 
 def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwargs):
-    """Load a RANGE / RANGE+ location encoder running on MI355X.
+    """Load a RANGE / RANGE+ (or plain SatCLIP) location encoder running on MI355X.
 
     Args:
-        model_name: 'RANGE' or 'RANGE+'.
+        model_name: 'RANGE', 'RANGE+' or 'SatCLIP' (the encoder alone, range.py:117-122).
         pretrained_path: SatCLIP checkpoint (e.g. satclip-vit16-l40.ckpt).
         device: 'cuda' / 'cuda:N'.
         **kwargs: ``db_path`` (required) - the range_db_*.npz bank; ``beta`` (RANGE+, default 0.5).

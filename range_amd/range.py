@@ -36,12 +36,13 @@ def _device_of(spec) -> torch.device:
     return dev
 
 
-def make_engine(enc: EncoderParams, bank: PreparedBank, device, row_offset: int = 0):
+def make_engine(enc: EncoderParams, bank: Optional[PreparedBank], device, row_offset: int = 0):
     eng = _native.HipEngine(device)
     mode = _native.SH_ANALYTIC if enc.harmonics_calculation == "analytic" else _native.SH_CLOSED_FORM
     eng.set_encoder(enc.legendre_polys, enc.hidden, enc.num_hidden_layers, enc.embed_dim, mode,
                     enc.weights, enc.biases)
-    eng.set_bank(bank.keys, bank.values, bank.xyz, row_offset)
+    if bank is not None:
+        eng.set_bank(bank.keys, bank.values, bank.xyz, row_offset)
     return eng
 
 
@@ -76,8 +77,18 @@ class LocationEncoder(nn.Module):
             self.n_bank_rows = bank.n_rows
             self._device = _device_of(args.device)
             self.engine = make_engine(enc, bank, self._device)
+        elif self.location_model_name == "SatCLIP":                     # range.py:117-122
+            print("Using SatCLIP")
+            enc = read_checkpoint(args.pretrained_path)
+            if enc.embed_dim != 256:
+                raise ValueError(f"checkpoint embed_dim {enc.embed_dim}: only 256 is implemented")
+            self.location_feature_dim = 256
+            self._model_id = None
+            self.encoder_params = enc
+            self._device = _device_of(args.device)
+            self.engine = make_engine(enc, None, self._device)
         else:
-            # the reference dispatches 11 more encoder families here (range.py:117-200); they are
+            # the reference dispatches 10 more encoder families here (range.py:124-200); they are
             # unrelated baselines and out of scope for this engine
             raise NotImplementedError(f"{self.location_model_name} not implemented")
         self.eval()
@@ -101,6 +112,13 @@ class LocationEncoder(nn.Module):
         (range.py:222/240).  ``return_device=True`` returns the device tensor instead (no D2H)."""
         x = self._coords(coords)
         B = x.shape[0]
+        if self._model_id is None:
+            # plain SatCLIP: the un-normalised (B,256) float64 embedding, a device tensor like
+            # the reference's (range.py:244-245)
+            if B == 0:
+                return torch.empty((0, 256), dtype=torch.float64, device=x.device)
+            return torch.cat([self.engine.encode_raw(x[i:i + self.chunk_size])
+                              for i in range(0, B, self.chunk_size)])
         beta = 1.0 if self._model_id == _native.MODEL_RANGE else float(self.args.beta)
         out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
         # (B == 0: nothing to launch; the reference returns an empty (0,1280) array as well)
@@ -112,10 +130,35 @@ class LocationEncoder(nn.Module):
         return out.cpu().numpy()
 
     @torch.no_grad()
+    def sweep(self, coords, betas, return_device: bool = False):
+        """RANGE+ embeddings of the same queries for several beta values (BASELINE config
+        "beta sweep").  beta only enters the blend of range.py:238, so the semantic retrieval H
+        and the geographic retrieval G are computed ONCE (two pass-2 launches instead of one per
+        beta) and blended per beta with the reference's float32 rounding.
+        Returns an array (len(betas), B, 1280) float64 (host ndarray, or device tensor)."""
+        if self._model_id != _native.MODEL_RANGE_PLUS:
+            raise ValueError("sweep() is defined for RANGE+ only")
+        betas = [float(b) for b in betas]
+        x = self._coords(coords)
+        B = x.shape[0]
+        out = torch.empty((len(betas), B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
+        eng = self.engine
+        for i in range(0, B, self.chunk_size):
+            e64, e32, xq = eng.encode(x[i:i + self.chunk_size])
+            st = eng.scan_stats(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO)
+            H = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 1.0, st)
+            G = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 0.0, st)
+            for j, b in enumerate(betas):
+                out[j, i:i + e64.shape[0]] = eng.finalize(eng.blend(G, H, b), e64)
+        return out if return_device else out.cpu().numpy()
+
+    @torch.no_grad()
     def topk(self, coords, k: int = 16):
         """Side channel: the k bank rows most similar (cosine, semantic keys) to each query,
         descending; returns (values (B,k) float32, indices (B,k) int64) device tensors."""
         x = self._coords(coords)
+        if self._model_id is None:
+            raise ValueError("topk() needs a bank (RANGE / RANGE+)")
         vals, idxs = [], []
         for i in range(0, x.shape[0], self.chunk_size):
             _, e32, xq = self.engine.encode(x[i:i + self.chunk_size])

@@ -365,3 +365,33 @@ def test_save_embeddings_driver(tmp_path):
     outs = list(EmbeddingPipeline(m, depth=3).run([q[:10], q[10:11], q[11:500]]))
     assert [o.shape[0] for o in outs] == [10, 1, 489]
     np.testing.assert_allclose(np.concatenate(outs), ref[:500], rtol=0, atol=2e-6)
+
+
+def test_beta_sweep_and_satclip_mode(tmp_path):
+    """BASELINE config 5 (beta sweep): H and G computed once, blended per beta with the
+    reference's rounding - compared with the reference goldens for all five betas; and the plain
+    SatCLIP mode (range.py:117-122, 244-245) against the golden un-normalised embedding."""
+    from range_amd import load_model
+    z = np.load(os.path.join(GOLDEN, "e2e_L40_H256_N1537.npz"))
+    ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=40, hidden=256, seed=int(z["weight_seed"]))
+    db = synth.write_bank(str(tmp_path / "db.npz"), int(z["bank_rows"]), int(z["bank_seed"]))
+    q = torch.from_numpy(z["lonlat"]).to("cuda:0")
+    m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db)
+    betas = (0.0, 0.25, 0.5, 0.75, 1.0)
+    sw = m.sweep(q, betas)
+    assert sw.shape == (5, q.shape[0], 1280) and sw.dtype == np.float64
+    for j, b in enumerate(betas):
+        np.testing.assert_allclose(sw[j], z[f"rangeplus_beta{b}"], rtol=0, atol=2e-5)
+        one = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=b)(q)
+        np.testing.assert_allclose(sw[j], one, rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        load_model("RANGE", pretrained_path=ck, device="cuda:0", db_path=db).sweep(q, betas)
+    # SatCLIP mode
+    g = np.load(os.path.join(GOLDEN, "enc_closedform_L16_H128_n3.npz"))
+    ck2 = synth.write_checkpoint(str(tmp_path / "enc2.ckpt"), L=16, hidden=128, num_hidden_layers=3,
+                                 seed=int(g["seed"]), harmonics_calculation="closed-form")
+    s = load_model("SatCLIP", pretrained_path=ck2, device="cuda:0")
+    assert s.location_feature_dim == 256
+    e = s(torch.from_numpy(g["lonlat"]).to("cuda:0"))
+    assert torch.is_tensor(e) and e.is_cuda and e.dtype == torch.float64 and e.shape == g["embedding"].shape
+    np.testing.assert_allclose(e.cpu().numpy(), g["embedding"], rtol=0, atol=1e-11)

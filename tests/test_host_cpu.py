@@ -39,6 +39,8 @@ def test_loader_errors_match_reference(tmp_path):
         load_model("RANGE++", pretrained_path=ck, device="cuda", db_path=db)
     with pytest.raises(NotImplementedError):             # range.py:199-200
         load_model("NoSuchModel", pretrained_path=ck)
+    with pytest.raises(NotImplementedError):             # the 10 unrelated baseline encoders
+        load_model("GeoCLIP", pretrained_path=ck)
     if not torch.cuda.is_available():
         # the product has no CPU path and must say so loudly
         with pytest.raises(RuntimeError):
