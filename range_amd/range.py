@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import _native
-from .bank import PreparedBank, load_bank
+from .bank import PreparedBank
+from .bankfile import load_any as load_bank
 from .ckpt import EncoderParams, read_checkpoint
 
 TEMP_RANGE = 15.0        # range/range.py:103

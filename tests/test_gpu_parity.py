@@ -395,3 +395,15 @@ def test_beta_sweep_and_satclip_mode(tmp_path):
     e = s(torch.from_numpy(g["lonlat"]).to("cuda:0"))
     assert torch.is_tensor(e) and e.is_cuda and e.dtype == torch.float64 and e.shape == g["embedding"].shape
     np.testing.assert_allclose(e.cpu().numpy(), g["embedding"], rtol=0, atol=1e-11)
+
+
+def test_prepared_bankfile_gives_identical_results(tmp_path):
+    from range_amd import load_model
+    from range_amd.bankfile import convert_npz
+    ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 1234, 3)
+    rb = convert_npz(db, str(tmp_path / "db.rbank"))
+    q = torch.from_numpy(synth.make_queries(200, seed=2)).to("cuda:0")
+    a = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db)(q)
+    b = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=rb)(q)
+    assert np.array_equal(a, b)

@@ -122,3 +122,25 @@ def test_no_foreign_m0_writes(tmp_path):
             elif not in_asm and re.search(r"\bm0\b", line.split(";")[0]):
                 raise AssertionError(f"{name}: compiler-generated M0 access: {line.strip()}")
     assert checked >= 6
+
+
+def test_bankfile_roundtrip_and_shards(tmp_path):
+    from range_amd.bankfile import convert_npz, is_bankfile, load_any, load_bankfile
+    db = synth.write_bank(str(tmp_path / "db.npz"), 1003, 9)
+    ref = load_bank(db)
+    rb = convert_npz(db, str(tmp_path / "db.rbank"))
+    assert is_bankfile(rb) and not is_bankfile(db)
+    b = load_bankfile(rb, verify=True)
+    for x, y in ((b.keys, ref.keys), (b.values, ref.values), (b.xyz, ref.xyz)):
+        assert x.dtype == np.float32 and np.array_equal(np.asarray(x), y)
+    sh = load_bankfile(rb, rows=(250, 777))
+    assert sh.n_rows == 527 and np.array_equal(np.asarray(sh.values), ref.values[250:777])
+    assert np.array_equal(np.asarray(load_any(rb, (5, 9)).xyz), np.asarray(load_any(db, (5, 9)).xyz))
+    with pytest.raises(ValueError):
+        load_bankfile(rb, rows=(0, 5000))
+    # a flipped byte is caught by the checksum
+    raw = bytearray(open(rb, "rb").read())
+    raw[4096 + 17] ^= 0xFF
+    open(str(tmp_path / "bad.rbank"), "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        load_bankfile(str(tmp_path / "bad.rbank"), verify=True)
