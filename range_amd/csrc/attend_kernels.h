@@ -109,11 +109,18 @@ __device__ __forceinline__ void load_qfrag(QFrag& f, const float* ehat, const fl
 // MFMA: the operands here come from LDS reads and long-lived registers (never a just-executed
 // VALU write; the first MFMA of a chain still carries `s_nop 1`), and a chain ends with
 // QKAcc::fence() before any non-MFMA instruction may read the results.
+//
+// WAR hazard on the A/B operands (measured on gfx950, tools/check_mfma_war.py): the compiler
+// treats an asm statement's inputs as dead once the statement has issued and may give their
+// registers to the very next VALU instruction; an MFMA is still reading them then, and the
+// product comes out wrong (deterministically).  One wait state after the MFMA was enough in every
+// experiment; each asm MFMA below carries a trailing `s_nop 1` (two), and tests/test_host_cpu.py checks the
+// generated code for MFMA sources written by the following instruction.
 __device__ __forceinline__ void mfma_v_first(f32x4& d, float a, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\ts_nop 1" : "=&v"(d) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_v(f32x4& d, float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 1" : "+v"(d) : "v"(a), "v"(b));
 }
 // (8-pass MFMA result -> VALU read needs 11 wait states: QKAcc::fence gives 16.)
 
@@ -497,7 +504,7 @@ __global__ void merge_topk_kernel(const float* cval, const int32_t* cidx32, cons
 // same reason as mfma_v - the builtin lets hipcc migrate accumulator tiles between the AGPR and
 // VGPR halves of the register file inside the loop.
 __device__ __forceinline__ void mfma_a(f32x4& acc, float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 1" : "+a"(acc) : "v"(a), "v"(b));
 }
 
 // 8 bank rows x 1024 columns of w @ V for this wave's 16 queries, as 16 steps of 8 MFMAs (4

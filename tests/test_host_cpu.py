@@ -122,6 +122,14 @@ def test_no_foreign_m0_writes(tmp_path):
             elif not in_asm and re.search(r"\bm0\b", line.split(";")[0]):
                 raise AssertionError(f"{name}: compiler-generated M0 access: {line.strip()}")
     assert checked >= 6
+    # second check on the same assembly: no instruction right behind an inline-asm MFMA writes one
+    # of its source registers (WAR hazard measured on gfx950, see attend_kernels.h mfma_v)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_mfma_war", os.path.join(REPO, "tools", "check_mfma_war.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.check(str(out), ["attend_kernel", "scan_stats_kernel"])
+    assert not bad, bad[:5]
 
 
 def test_bankfile_roundtrip_and_shards(tmp_path):
