@@ -27,13 +27,44 @@ class EncoderParams:
 _POPPED = ("eval_downstream", "air_temp_data_path", "election_data_path")
 
 
-def read_checkpoint(path: str) -> EncoderParams:
+class _TolerantPickle:
+    """pickle module stand-in for torch.load: classes of packages that are not installed
+    (a Lightning checkpoint may reference lightning / pytorch_lightning helper types such as
+    ``AttributeDict``) are replaced by plain containers instead of failing the load.  Only used
+    after the safe ``weights_only=True`` load has refused the file."""
+    import pickle as _p
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                if "Dict" in name or "dict" in name or "Namespace" in name:
+                    return type(name, (dict,), {"__setstate__": lambda self, st: self.update(st)
+                                                if isinstance(st, dict) else None})
+                return type(name, (), {"__init__": lambda self, *a, **k: None,
+                                       "__setstate__": lambda self, st: None,
+                                       "__call__": lambda self, *a, **k: None})
+
+    load = staticmethod(_p.load)
+    __name__ = "pickle"
+
+
+def _load_file(path: str):
     try:
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        return torch.load(path, map_location="cpu", weights_only=True)
     except Exception:
         # Lightning checkpoints may carry non-tensor objects (same trust model as the
         # reference's plain torch.load, satclip/load.py:4)
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            return torch.load(path, map_location="cpu", weights_only=False)
+        except (ImportError, AttributeError, ModuleNotFoundError):
+            return torch.load(path, map_location="cpu", weights_only=False,
+                              pickle_module=_TolerantPickle)
+
+
+def read_checkpoint(path: str) -> EncoderParams:
+    ckpt = _load_file(path)
     hp = dict(ckpt["hyper_parameters"])
     for k in _POPPED:
         hp.pop(k)   # KeyError if absent, exactly like satclip/load.py:5-7

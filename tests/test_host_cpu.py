@@ -152,3 +152,29 @@ def test_bankfile_roundtrip_and_shards(tmp_path):
     open(str(tmp_path / "bad.rbank"), "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="checksum"):
         load_bankfile(str(tmp_path / "bad.rbank"), verify=True)
+
+
+def test_checkpoint_with_uninstalled_helper_classes(tmp_path):
+    """A Lightning checkpoint may pickle helper types of packages that are absent here
+    (e.g. lightning.fabric.utilities.data.AttributeDict); the reader must still get the
+    hyper-parameters and tensors out."""
+    import sys
+    import types
+    mod = types.ModuleType("fakelightning_pkg")
+    class AttributeDict(dict):
+        pass
+    AttributeDict.__module__ = "fakelightning_pkg"
+    AttributeDict.__qualname__ = "AttributeDict"
+    mod.AttributeDict = AttributeDict
+    sys.modules["fakelightning_pkg"] = mod
+    try:
+        c = synth.make_checkpoint(L=10, hidden=64)
+        c["hyper_parameters"] = AttributeDict(c["hyper_parameters"])
+        c["callbacks"] = {"note": AttributeDict(a=1)}
+        p = str(tmp_path / "lightning_like.ckpt")
+        torch.save(c, p)
+    finally:
+        del sys.modules["fakelightning_pkg"]
+    enc = read_checkpoint(p)
+    assert (enc.legendre_polys, enc.hidden, enc.embed_dim) == (10, 64, 256)
+    assert np.array_equal(enc.weights[0], synth.make_encoder_weights(10, 64)["layers.0.weight"])
