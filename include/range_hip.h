@@ -110,6 +110,14 @@ int range_scan_stats(range_ctx* ctx, const float* ehat32_dev, const float* xq32_
                      float tau_sem, float tau_geo, float* stats_dev, int topk,
                      float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 
+/* Small-batch top-k, the HBM-streaming form of the keys scan (no reference counterpart; north star:
+ * "brute-force cosine-similarity top-k ... coalesced HBM-streaming kernel with per-wavefront
+ * running top-k").  Every wave streams its own 16-row key tiles against groups of 16 queries;
+ * meant for B up to a few dozen (each group of 16 queries re-streams the keys).  Same outputs and
+ * tie rule as the top-k of range_scan_stats. */
+int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
+                      float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
+
 /* Exact merge of per-shard statistics (row-sharded bank): parts_dev is (n_parts,B,4) as written
  * by range_scan_stats on each shard (e.g. after an all-gather); out_dev is (B,4). */
 int range_merge_stats(range_ctx* ctx, const float* parts_dev, int32_t n_parts, int64_t B,

@@ -27,7 +27,7 @@ SYMBOLS = (
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
-    "range_attend_diag", "range_encode_raw", "range_blend",
+    "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
 )
 
 
@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
     lib.range_attend_diag.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, i64, vp]
     lib.range_encode_raw.argtypes = [vp, vp, i64, vp, vp]
     lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
+    lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
     if lib.range_abi_version() != 1:
@@ -215,6 +216,16 @@ class HipEngine:
                                                    tau_sem, tau_geo, stats.data_ptr(), topk,
                                                    _ptr(tv), _ptr(ti), self._stream()))
         return (stats, tv, ti) if topk else stats
+
+    def topk_stream(self, e32: torch.Tensor, k: int):
+        """Small-batch top-k by the HBM-streaming kernel (see range_hip.h)."""
+        self._t(e32, torch.float32, (KEY_DIM,))
+        B = e32.shape[0]
+        tv = self._empty((B, k), torch.float32)
+        ti = self._empty((B, k), torch.int64)
+        _check(self.lib, self.lib.range_topk_stream(self._h, e32.data_ptr(), B, k, tv.data_ptr(),
+                                                    ti.data_ptr(), self._stream()))
+        return tv, ti
 
     def merge_stats(self, parts: torch.Tensor) -> torch.Tensor:
         if parts.dim() != 3 or parts.shape[2] != 4:

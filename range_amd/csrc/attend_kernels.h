@@ -452,6 +452,230 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-batch top-k: the HBM-streaming form of the keys scan.
+//
+// For a handful of queries the scan is bound by streaming the 104 MB of keys, not by MFMA, and
+// the 64-queries-per-workgroup decomposition above wastes the machine (a 16-query batch keeps one
+// wave in four busy).  Here every WAVE streams its own 16-row key tiles (wave-private LDS ring of
+// two tiles filled by LDS-DMA, no workgroup barrier in the loop) against the SAME group of <= 16
+// queries held in registers, and keeps a running top-K per lane in registers as 64-bit keys
+// (ordered value bits << 32 | ~row): larger key = larger similarity, ties -> lower row index.
+// Lists are merged per query across the 4 lane groups (shuffles), the 4 waves (LDS) and finally
+// the workgroups (merge_lists_kernel).  blockIdx.y = query group (16 queries each).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long topk_key(float v, uint32_t row) {
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ float topk_key_val(unsigned long long k) {
+    const uint32_t o = (uint32_t)(k >> 32);
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ uint32_t topk_key_row(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
+
+struct KeyList {                       // sorted descending; 0 = empty slot
+    unsigned long long k[MAX_TOPK];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) k[i] = 0ull;
+    }
+    __device__ __forceinline__ void push(unsigned long long x) {
+        if (x > k[MAX_TOPK - 1]) {
+            k[MAX_TOPK - 1] = x;
+#pragma unroll
+            for (int i = MAX_TOPK - 1; i > 0; --i) {
+                const unsigned long long a = k[i - 1], b = k[i];
+                k[i - 1] = a > b ? a : b;
+                k[i] = a > b ? b : a;
+            }
+        }
+    }
+    __device__ __forceinline__ void pop() {
+#pragma unroll
+        for (int i = 0; i + 1 < MAX_TOPK; ++i) k[i] = k[i + 1];
+        k[MAX_TOPK - 1] = 0ull;
+    }
+};
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)x, m), hi = __shfl_xor((uint32_t)(x >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// merge the sorted lists held by lanes (j, g=0..3) of one query j: afterwards every such lane
+// holds the same top-MAX_TOPK list.  Keys are unique (the row is part of the key).
+__device__ __forceinline__ void merge_lane_groups(KeyList& L) {
+    KeyList R;
+#pragma unroll
+    for (int i = 0; i < MAX_TOPK; ++i) {
+        const unsigned long long h = L.k[0];
+        unsigned long long m = h;
+        unsigned long long o = shfl_xor_u64(m, 16); m = o > m ? o : m;
+        o = shfl_xor_u64(m, 32); m = o > m ? o : m;
+        R.k[i] = m;
+        if (h == m && m != 0ull) L.pop();
+    }
+    L = R;
+}
+
+struct TopkStreamArgs {
+    const float* keys;       // (n_pad,256)
+    const float* ehat;       // (B,256)
+    unsigned long long* cand;   // (n_groups, n_wg, 16 queries, 16) keys
+    int64_t B;
+    int64_t n_valid;
+    int32_t n_blocks;
+};
+
+constexpr int TOPKS_LDS_BYTES = 4 * 2 * BLK * KEY_DIM * 4;   // 4 waves x 2 tiles x 16 KB
+
+__global__ __launch_bounds__(256) void topk_stream_kernel(TopkStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * 2 * KT_BYTES;
+    const char* my = smem + wave * 2 * KT_BYTES;
+
+    const int group = blockIdx.y;
+    const int64_t q = (int64_t)group * 16 + (lane & 15);
+    const int n_waves = gridDim.x * 4;
+    const int w_id = blockIdx.x * 4 + wave;
+    // one tile = 16 rows = 16 DMA instructions (4 groups of 4 rows, swizzled source)
+    auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
+        const float* src = a.keys + (int64_t)tile * BLK * KEY_DIM;
+#pragma unroll
+        for (int gr = 0; gr < 4; ++gr) {
+            dma_group_begin(lds0 + slot * KT_BYTES + gr * 4096);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dma_b128_q(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i)) << 4), i);
+        }
+    };
+    int tile = w_id, slot = 0;
+    if (tile < a.n_blocks) issue_tile(tile, 0);      // first keys on their way before anything else
+    QFrag f;
+    load_qfrag(f, a.ehat, a.ehat, a.B, q, g);        // (xq unused: semantic head only)
+    pin_qfrag(f);
+    KAddr kaddr;
+    kaddr.init(lane);
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
+    KeyList L;
+    L.init();
+    for (; tile < a.n_blocks; tile += n_waves) {
+        const int next = tile + n_waves;
+        if (next < a.n_blocks) {
+            issue_tile(next, slot ^ 1);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        QKAcc c;
+        const char* kt = my + slot * KT_BYTES;
+        qk_mfma<false>(kt, qk_first_reads<false>(kt, kt, kaddr), kaddr, f, c,
+                       [](int) __attribute__((always_inline)) {});
+        c.fence();
+        const int64_t row0 = (int64_t)tile * BLK;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + prow[r];
+            if (row < a.n_valid) L.push(topk_key(c.sem(r), (uint32_t)row));
+        }
+        // all LDS reads of this tile are complete (their results fed the MFMAs above) before
+        // the next iteration's DMA may overwrite the slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot ^= 1;
+    }
+    // per-query merge: lane groups -> waves -> one list per workgroup
+    merge_lane_groups(L);
+    __syncthreads();                                   // ring no longer needed: reuse LDS
+    unsigned long long* sh = reinterpret_cast<unsigned long long*>(smem);   // [wave][16 q][16]
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) sh[(wave * 16 + (lane & 15)) * MAX_TOPK + i] = L.k[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        KeyList M;
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[(g * 16 + (lane & 15)) * MAX_TOPK + i];
+        merge_lane_groups(M);
+        if (g == 0) {
+            unsigned long long* o = a.cand + (((int64_t)group * gridDim.x + blockIdx.x) * 16 + (lane & 15)) * MAX_TOPK;
+#pragma unroll
+            for (int i = 0; i < MAX_TOPK; ++i) o[i] = M.k[i];
+        }
+    }
+}
+
+// top list of the 64 sorted lists held by the lanes of one wave (no barrier: shuffles only)
+__device__ __forceinline__ void merge_wave(KeyList& L) {
+    KeyList R;
+#pragma unroll
+    for (int i = 0; i < MAX_TOPK; ++i) {
+        const unsigned long long h = L.k[0];
+        unsigned long long m = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = shfl_xor_u64(m, off);
+            m = o > m ? o : m;
+        }
+        R.k[i] = m;
+        if (h == m && m != 0ull) L.pop();
+    }
+    L = R;
+}
+
+// one workgroup per query: each thread owns one sorted candidate list (one per stream
+// workgroup, <= 512); every wave reduces its 64 lists, wave 0 reduces the per-wave results.
+__global__ __launch_bounds__(512) void merge_lists_kernel(const unsigned long long* cand, int n_parts,
+                                                          int64_t B, int k, int64_t row_offset,
+                                                          float* oval, int64_t* oidx) {
+    __shared__ unsigned long long sh[8 * MAX_TOPK];
+    const int n_wv = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = blockIdx.x;
+    const int64_t group = q >> 4;
+    const int p = threadIdx.x;
+    KeyList L;
+    L.init();
+    if (p < n_parts) {
+        const unsigned long long* src = cand + ((group * n_parts + p) * 16 + (q & 15)) * MAX_TOPK;
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) L.k[i] = src[i];
+    }
+    merge_wave(L);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = L.k[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        KeyList M;
+        M.init();
+        if (lane < n_wv) {
+#pragma unroll
+            for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
+        }
+        merge_wave(M);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < MAX_TOPK; ++i) {
+                if (i < k) {
+                    const unsigned long long mm = M.k[i];
+                    oval[q * k + i] = mm ? topk_key_val(mm) : -INFINITY;
+                    oidx[q * k + i] = mm ? (int64_t)topk_key_row(mm) + row_offset : (int64_t)-1;
+                }
+            }
+        }
+    }
+}
+
 // (n_parts,B,4) -> (B,4): exact log-sum-exp merge, fixed order.
 __global__ void merge_stats_kernel(const float* parts, int n_parts, int64_t B, float* out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

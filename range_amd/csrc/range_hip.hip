@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +90,7 @@ struct range_ctx {
     // workspace
     DevBuf<float> ws_stats_parts, ws_slabs, ws_stats, ws_ehat32, ws_xq, ws_partial, ws_cand_val;
     DevBuf<int32_t> ws_cand_idx;
+    DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<double> ws_ehat64;
     int last_qtiles = 0, last_splits = 0;
     // profiling: event pairs per kernel kind
@@ -141,16 +143,19 @@ struct DeviceGuard {
 // (512 registers, 129 KB LDS), 4 for pass 1 (33 KB LDS, <= 128 VGPRs).
 int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits) {
     const double slots = (double)n_cu * wg_per_cu;
-    int best = 1;
-    double best_score = -1.0;
-    for (int ns = 1; ns <= max_splits; ++ns) {
-        if (ns > 1 && (int64_t)ns * 4 > n_blocks) break;   // keep >= 4 blocks per split
+    const int cap = std::max(1, std::min(max_splits, n_blocks / 4));   // >= 4 blocks per split
+    // small batches: first of all give every slot a workgroup
+    const int ns_min = std::min(cap, (int)std::ceil(slots / n_qtiles));
+    int best = ns_min;
+    double best_score = -1e9;
+    for (int ns = ns_min; ns <= cap; ++ns) {
         const double total = (double)n_qtiles * ns;
         const double rounds = std::ceil(total / slots);
         double score = total / (rounds * slots);            // fill of the rounds
         if (rounds < 4) score *= 0.85 + 0.0375 * rounds;    // few rounds: ragged finish hurts more
-        score -= 0.002 * ns;                                // partial-result traffic
+        score -= 0.002 * (ns - ns_min);                     // partial-result traffic
         if (score > best_score) { best_score = score; best = ns; }
+        if (ns - ns_min > 64) break;
     }
     return best;
 }
@@ -469,7 +474,10 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
     // top-k candidates cost 512 B per (query, split): keep the split count low in that variant
-    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true, topk > 0 ? 16 : 128);
+    // (small batches are HBM-bound: many splits so that every CU streams a share of the keys)
+    const int few = B <= 4 * QTILE;
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true,
+                            few ? 2048 : (topk > 0 ? 16 : 128));
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
@@ -507,6 +515,40 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
                            B, 4 * MAX_TOPK, topk, c->row_offset, topk_val, topk_idx);
         HIP_TRY(hipGetLastError());
     }
+    return RANGE_OK;
+}
+
+int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
+                      int64_t* topk_idx, range_stream_t stream) {
+    if (!c || !ehat32 || !topk_val || !topk_idx) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
+    if (B <= 0 || k <= 0 || k > MAX_TOPK) return fail(RANGE_ERR_INVALID, "bad B or k");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int n_groups = (int)((B + 15) / 16);
+    const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
+    // one candidate list per workgroup, one merge thread per list (<= 512)
+    const int n_wg = std::max(1, std::min(c->n_cu, (n_blocks + 3) / 4));
+    HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_wg * 16 * MAX_TOPK));
+    TopkStreamArgs a{};
+    a.keys = c->d_keys.p;
+    a.ehat = ehat32;
+    a.cand = c->ws_cand_keys.p;
+    a.B = B;
+    a.n_valid = c->n_rows;
+    a.n_blocks = n_blocks;
+    int rc = set_dyn_lds(topk_stream_kernel, TOPKS_LDS_BYTES);
+    if (rc) return rc;
+    {
+        ProfScope ps(c, RANGE_PROF_SCAN_STATS, s);
+        hipLaunchKernelGGL(topk_stream_kernel, dim3((unsigned)n_wg, (unsigned)n_groups), dim3(256),
+                           TOPKS_LDS_BYTES, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)B), dim3(n_wg > 256 ? 512 : 256), 0, s, c->ws_cand_keys.p, n_wg, B,
+                       (int)k, c->row_offset, topk_val, topk_idx);
+    HIP_TRY(hipGetLastError());
     return RANGE_OK;
 }
 

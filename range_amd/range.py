@@ -52,6 +52,8 @@ class LocationEncoder(nn.Module):
 
     #: queries per engine call; bounds the per-call workspace (split slabs of chunk x 4 KB)
     chunk_size = 16384
+    #: topk(): batches up to this size use the HBM-streaming kernel, larger ones the MFMA scan
+    topk_stream_max = 32
 
     def __init__(self, args):
         super().__init__()
@@ -161,6 +163,10 @@ class LocationEncoder(nn.Module):
         if self._model_id is None:
             raise ValueError("topk() needs a bank (RANGE / RANGE+)")
         vals, idxs = [], []
+        if 0 < x.shape[0] <= self.topk_stream_max:
+            # a handful of queries: the HBM-streaming kernel (every wave streams its own key tiles)
+            _, e32, _ = self.engine.encode(x)
+            return self.engine.topk_stream(e32, k)
         for i in range(0, x.shape[0], self.chunk_size):
             _, e32, xq = self.engine.encode(x[i:i + self.chunk_size])
             _, tv, ti = self.engine.scan_stats(e32, xq, float(self.args.temp), 0.0, topk=k)

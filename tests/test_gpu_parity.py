@@ -407,3 +407,23 @@ def test_prepared_bankfile_gives_identical_results(tmp_path):
     a = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db)(q)
     b = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=rb)(q)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,B,k", [(500, 1, 16), (1537, 16, 5), (20000, 17, 16), (100000, 64, 16),
+                                   (9, 3, 4), (16, 33, 1), (4100, 48, 8)])
+def test_topk_stream_kernel_vs_oracle(N, B, k):
+    """Small-batch HBM-streaming top-k (range_topk_stream): indices bit-exact vs the float64
+    oracle (near-ties as in test_topk_vs_oracle), same result as the MFMA-scan top-k."""
+    bank, obank, w, enc, q, e = _synthetic_case(N, B)
+    eng = _engine(None, bank, row_offset=0)
+    e32 = _dev(e, torch.float32)
+    tv, ti = eng.topk_stream(e32, k)
+    s, _ = O.logits64(e, q, obank)
+    kk = min(k, N)
+    nbad = _topk_ok(ti.cpu().numpy()[:, :kk], tv.cpu().numpy()[:, :kk], s, kk)
+    assert nbad <= max(1, B * kk // 1000)
+    if N < k:
+        assert np.all(ti.cpu().numpy()[:, N:] == -1)
+    xq4 = np.zeros((B, 4), np.float32)
+    _, tv2, ti2 = eng.scan_stats(e32, _dev(xq4), 12.0, 0.0, topk=k)
+    assert torch.equal(ti, ti2) and torch.equal(tv, tv2)
