@@ -150,9 +150,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    att_ms, att_n = eng.profile_read(_native.RANGE_PROF_ATTEND if hasattr(_native, "RANGE_PROF_ATTEND") else 2)
-    st_ms, st_n = eng.profile_read(1)
-    en_ms, en_n = eng.profile_read(0)
+    att_ms, att_n = eng.profile_read(_native.PROF_ATTEND)
+    st_ms, st_n = eng.profile_read(_native.PROF_SCAN_STATS)
+    en_ms, en_n = eng.profile_read(_native.PROF_ENCODER)
     eng.profile_enable(False)
     assert att_n >= a.steps and att_n % a.steps == 0, (att_n, a.steps)   # sharded: one per chunk
     assert bool(torch.isfinite(out).all())

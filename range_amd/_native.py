@@ -20,6 +20,7 @@ KEY_DIM, VAL_DIM, OUT_DIM = 256, 1024, 1280
 SH_ANALYTIC, SH_CLOSED_FORM = 0, 1
 MODEL_RANGE, MODEL_RANGE_PLUS = 0, 1
 MAX_TOPK = 16
+PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND = 0, 1, 2   # range_profile_read(which)
 
 # every symbol include/range_hip.h declares
 SYMBOLS = (

@@ -41,7 +41,6 @@ constexpr int BLK = 16;          // bank rows per block
 constexpr int MAX_TOPK = 16;
 constexpr float NEG_BIG = -1.0e30f;
 
-#define RANGE_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RANGE_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // MFMA row index i (0..15) of the transposed logit tile -> bank row inside the 16-row block.
@@ -264,23 +263,6 @@ __device__ __forceinline__ void issue_k_tile(const float* keys, const float* xyz
         dma_b128(keys + (row0 + R) * KEY_DIM, (uint32_t)((swz ^ rr) << 4), kt_lds + R * (KEY_DIM * 4));
     }
     dma_b32(xyz4 + row0 * 4, (uint32_t)(lane << 2), xt_lds);
-}
-
-// Piece-wise forms (one DMA each) so that the issue can be spread between MFMAs.
-__device__ __forceinline__ void issue_k_row(const float* keys, int64_t row0, uint32_t kt_lds,
-                                            int wave, int swz, int rr) {
-    const int R = 4 * wave + rr;
-    dma_b128(keys + (row0 + R) * KEY_DIM, (uint32_t)((swz ^ rr) << 4), kt_lds + R * (KEY_DIM * 4));
-}
-__device__ __forceinline__ void issue_x_tile(const float* xyz4, int64_t row0, uint32_t xt_lds,
-                                             int lane) {
-    dma_b32(xyz4 + row0 * 4, (uint32_t)(lane << 2), xt_lds);
-}
-__device__ __forceinline__ void issue_v_piece(const float* values, int64_t row0, uint32_t vslot_lds,
-                                              int wave, int lane, int ii) {
-    const int i = 8 * wave + ii;
-    dma_b128(values + (row0 + (i >> 2)) * VAL_DIM + (i & 3) * 256, (uint32_t)(lane << 4),
-             vslot_lds + i * 1024);
 }
 
 // One 8-row half block of V (32 KB, row-major, linear): 32 pieces of 1 KB, 8 per wave.
