@@ -427,3 +427,21 @@ def test_topk_stream_kernel_vs_oracle(N, B, k):
     xq4 = np.zeros((B, 4), np.float32)
     _, tv2, ti2 = eng.scan_stats(e32, _dev(xq4), 12.0, 0.0, topk=k)
     assert torch.equal(ti, ti2) and torch.equal(tv, tv2)
+
+
+def test_encoder_edge_coordinates():
+    """Poles, antimeridian, equator/prime-meridian crossings, out-of-range wrap: the fused encoder
+    must agree with the float64 oracle everywhere (the recurrence is stable at the poles, where the
+    reference's expanded polynomials are not)."""
+    w, enc = _params(40, 512, 2, 1234, "analytic")
+    eng = _engine(enc)
+    q = np.array([[0.0, 90.0], [0.0, -90.0], [137.0, 90.0], [-180.0, 0.0], [180.0, 0.0],
+                  [179.9999999, 12.0], [-179.9999999, 12.0], [0.0, 0.0], [1e-12, -1e-12],
+                  [360.0, 10.0], [-45.0, 89.999999], [90.0, -89.999999], [12.3456789, 45.0]],
+                 dtype=np.float64)
+    e64, e32, xq = eng.encode(_dev(q))
+    ref = O.encode(q, w, 40, "analytic")
+    assert np.all(np.isfinite(e64.cpu().numpy()))
+    np.testing.assert_allclose(e64.cpu().numpy(), ref, rtol=0, atol=5e-12)
+    np.testing.assert_allclose(np.linalg.norm(e64.cpu().numpy(), axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1.2e-7)
