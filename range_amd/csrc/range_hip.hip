@@ -578,10 +578,12 @@ int range_merge_topk(range_ctx* c, const float* val_parts, const int64_t* idx_pa
     return RANGE_OK;
 }
 
-int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
-                 float tau_geo, float beta, const float* stats_global, float* partial,
-                 range_stream_t stream) {
-    if (!c || !ehat32 || !xq32 || !stats_global || !partial) return fail(RANGE_ERR_INVALID, "null argument");
+// pass 2 into the context's split slabs; when `partial` is non-null the slabs are then summed
+// (fixed order) into it, otherwise the caller consumes the slabs (n_splits_out of them) itself.
+static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                       float tau_geo, float beta, const float* stats_global, float* partial,
+                       int* n_splits_out, range_stream_t stream) {
+    if (!c || !ehat32 || !xq32 || !stats_global) return fail(RANGE_ERR_INVALID, "null argument");
     if (!(beta >= 0.f && beta <= 1.f)) return fail(RANGE_ERR_INVALID, "beta must be in [0,1]");
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
@@ -608,11 +610,21 @@ int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B
         }
     }
     HIP_TRY(hipGetLastError());
-    const int64_t total4 = B * (VAL_DIM / 4);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s,
-                       c->ws_slabs.p, a.n_splits, total4, partial);
-    HIP_TRY(hipGetLastError());
+    if (n_splits_out) *n_splits_out = a.n_splits;
+    if (partial) {
+        const int64_t total4 = B * (VAL_DIM / 4);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s,
+                           c->ws_slabs.p, a.n_splits, total4, partial);
+        HIP_TRY(hipGetLastError());
+    }
     return RANGE_OK;
+}
+
+int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                 float tau_geo, float beta, const float* stats_global, float* partial,
+                 range_stream_t stream) {
+    if (!partial) return fail(RANGE_ERR_INVALID, "null argument");
+    return attend_impl(c, ehat32, xq32, B, tau_sem, tau_geo, beta, stats_global, partial, nullptr, stream);
 }
 
 // Diagnostic (not part of the product path): same launch as range_attend with the instrumented
@@ -667,7 +679,6 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
         HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
         HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
         HIP_TRY(c->ws_stats.ensure((size_t)B * 4));
-        HIP_TRY(c->ws_partial.ensure((size_t)B * VAL_DIM));
     }
     const float tau_sem = model == RANGE_MODEL_RANGE ? 15.0f : 12.0f;   // range.py:103, 108
     const float tau_geo = model == RANGE_MODEL_RANGE ? 0.0f : 40.0f;    // range.py:109
@@ -676,10 +687,13 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
                           nullptr, nullptr, stream);
     if (rc) return rc;
-    rc = range_attend(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
-                      model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, c->ws_partial.p, stream);
+    // single GPU: the finalize kernel sums the split slabs itself (same fixed order as
+    // reduce_parts_kernel, so the result is bit-identical to attend + finalize)
+    int n_splits = 0;
+    rc = attend_impl(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
+                     model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, &n_splits, stream);
     if (rc) return rc;
-    return range_finalize(c, c->ws_partial.p, 1, c->ws_ehat64.p, B, out, stream);
+    return range_finalize(c, c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, out, stream);
 }
 
 int range_profile_enable(range_ctx* c, int32_t on) {
