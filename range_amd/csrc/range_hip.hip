@@ -473,11 +473,12 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
-    // top-k candidates cost 512 B per (query, split): keep the split count low in that variant
+    // top-k candidates cost 512 B per (query, split) and are merged by one thread per query:
+    // keep the split count low in that variant
     // (small batches are HBM-bound: many splits so that every CU streams a share of the keys)
     const int few = B <= 4 * QTILE;
     int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true,
-                            few ? 2048 : (topk > 0 ? 16 : 128));
+                            topk > 0 ? (few ? 64 : 16) : (few ? 2048 : 128));
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
