@@ -97,6 +97,18 @@ int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* eh
 int range_encode_raw(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* eraw64_dev,
                      range_stream_t stream);
 
+/* The reference's training-free coordinate encoders (load_model names 'Direct', 'Cartesian_3D',
+ * 'Wrap'; range/range.py:152-162, 170-173, 262-272).  float64, elementwise.
+ *   mode 0 Direct       : out (B,2) = (lon,lat)*pi/180                       (range.py:262-264)
+ *   mode 1 Cartesian_3D : out (B,3) = rad_to_cart of the above              (:265-268, utils/utils.py:11-16)
+ *   mode 2 Wrap         : out (B,4) = (cos lon, sin lon, cos lat, sin lat) of deg2rad
+ *                         (positional_encoding/wrap.py:20-29) */
+#define RANGE_COORD_DIRECT 0
+#define RANGE_COORD_CARTESIAN3D 1
+#define RANGE_COORD_WRAP 2
+int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev, int64_t B,
+                         double* out_dev, range_stream_t stream);
+
 /* Kernel B, pass 1.  Streaming log-sum-exp statistics of the temperature-scaled logits of
  * range/range.py:213-215 (semantic) and :231-234 (geographic) over THIS ctx's bank rows.
  *   tau_sem, tau_geo : temperatures (range.py:103, 108-109); tau_geo <= 0 disables the geo head

@@ -143,6 +143,25 @@ def rad_to_cart(locations: np.ndarray) -> np.ndarray:
     return np.stack([x, y, z], axis=1)
 
 
+def coord_features(lonlat: np.ndarray, model_name: str) -> np.ndarray:
+    """The training-free encoders of range/range.py:262-272 on (B,2) float64 (lon,lat) degrees.
+
+    'Direct' (:262-264, identity module :63-67): ``coords * math.pi/180`` = (x*pi)/180.
+    'Cartesian_3D' (:265-268): rad_to_cart of that, in numpy.
+    'Wrap' (positional_encoding/wrap.py:20-29): torch.deg2rad(x) = x * (pi/180 as one constant),
+    then (cos lon, sin lon, cos lat, sin lat)."""
+    x = np.asarray(lonlat, dtype=np.float64)
+    if model_name == "Wrap":
+        r = x * 0.017453292519943295
+        return np.stack([np.cos(r[:, 0]), np.sin(r[:, 0]), np.cos(r[:, 1]), np.sin(r[:, 1])], axis=1)
+    rad = x * math.pi / 180
+    if model_name == "Direct":
+        return rad
+    if model_name == "Cartesian_3D":
+        return rad_to_cart(rad)
+    raise NotImplementedError(model_name)
+
+
 # --------------------------------------------------------------------------------------------
 # R4  bank preparation  (range/range.py:78-100)
 # --------------------------------------------------------------------------------------------

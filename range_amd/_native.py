@@ -21,6 +21,8 @@ SH_ANALYTIC, SH_CLOSED_FORM = 0, 1
 MODEL_RANGE, MODEL_RANGE_PLUS = 0, 1
 MAX_TOPK = 16
 PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND = 0, 1, 2   # range_profile_read(which)
+COORD_DIRECT, COORD_CARTESIAN3D, COORD_WRAP = 0, 1, 2   # range_coord_features(mode)
+COORD_DIMS = {COORD_DIRECT: 2, COORD_CARTESIAN3D: 3, COORD_WRAP: 4}
 
 # every symbol include/range_hip.h declares
 SYMBOLS = (
@@ -29,6 +31,7 @@ SYMBOLS = (
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
+    "range_coord_features",
 )
 
 
@@ -79,6 +82,7 @@ def load_library() -> C.CDLL:
     lib.range_encode_raw.argtypes = [vp, vp, i64, vp, vp]
     lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
     if lib.range_abi_version() != 1:
@@ -192,6 +196,15 @@ class HipEngine:
         out = self._empty((B, KEY_DIM), torch.float64)
         _check(self.lib, self.lib.range_encode_raw(self._h, lonlat.data_ptr(), B, out.data_ptr(),
                                                    self._stream()))
+        return out
+
+    def coord_features(self, lonlat: torch.Tensor, mode: int) -> torch.Tensor:
+        """Training-free coordinate encoders (range.py:262-272): Direct / Cartesian_3D / Wrap."""
+        self._t(lonlat, torch.float64, (2,))
+        B = lonlat.shape[0]
+        out = self._empty((B, COORD_DIMS[mode]), torch.float64)
+        _check(self.lib, self.lib.range_coord_features(self._h, mode, lonlat.data_ptr(), B,
+                                                       out.data_ptr(), self._stream()))
         return out
 
     def blend(self, G: torch.Tensor, H: torch.Tensor, beta: float) -> torch.Tensor:

@@ -452,6 +452,50 @@ int range_encode_raw(range_ctx* c, const double* lonlat, int64_t B, double* eraw
     return encode_impl(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, eraw64, stream);
 }
 
+// Training-free coordinate encoders of the reference (range/range.py:262-272): one thread per
+// location, float64.  mode 0 'Direct' (:262-264): (lon,lat)*pi/180, evaluated as (x*pi)/180 like
+// the Python expression; mode 1 'Cartesian_3D' (:265-268, utils/utils.py:11-16): unit xyz of the
+// radians above; mode 2 'Wrap' (positional_encoding/wrap.py:20-29): cos/sin of torch.deg2rad(x)
+// = x * (pi/180) per column, ordered (cos lon, sin lon, cos lat, sin lat).
+__global__ void coord_features_kernel(int mode, const double* __restrict__ lonlat, int64_t n,
+                                      double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lon = lonlat[2 * i], lat = lonlat[2 * i + 1];
+    constexpr double PI = 3.141592653589793;
+    if (mode == 2) {
+        constexpr double PI_180 = 0.017453292519943295;
+        const double a = lon * PI_180, b = lat * PI_180;
+        out[4 * i + 0] = cos(a);
+        out[4 * i + 1] = sin(a);
+        out[4 * i + 2] = cos(b);
+        out[4 * i + 3] = sin(b);
+        return;
+    }
+    const double a = (lon * PI) / 180.0, b = (lat * PI) / 180.0;
+    if (mode == 0) {
+        out[2 * i + 0] = a;
+        out[2 * i + 1] = b;
+    } else {
+        const double cb = cos(b);
+        out[3 * i + 0] = cb * cos(a);
+        out[3 * i + 1] = cb * sin(a);
+        out[3 * i + 2] = sin(b);
+    }
+}
+
+int range_coord_features(range_ctx* c, int32_t mode, const double* lonlat, int64_t B, double* out,
+                         range_stream_t stream) {
+    if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 2) return fail(RANGE_ERR_INVALID, "coordinate encoder mode %d", mode);
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    DeviceGuard g(c->device);
+    hipLaunchKernelGGL(coord_features_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, mode, lonlat, B, out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
 int range_blend(range_ctx* c, const float* G, const float* H, float beta, int64_t B, float* out,
                 range_stream_t stream) {
     if (!c || !G || !H || !out) return fail(RANGE_ERR_INVALID, "null argument");

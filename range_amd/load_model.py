@@ -11,8 +11,10 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
     """Load a RANGE / RANGE+ (or plain SatCLIP) location encoder running on MI355X.
 
     Args:
-        model_name: 'RANGE', 'RANGE+' or 'SatCLIP' (the encoder alone, range.py:117-122).
-        pretrained_path: SatCLIP checkpoint (e.g. satclip-vit16-l40.ckpt).
+        model_name: 'RANGE', 'RANGE+', 'SatCLIP' (the encoder alone, range.py:117-122) or one of
+            the training-free encoders 'Direct', 'Cartesian_3D', 'Wrap' (range.py:152-173).
+        pretrained_path: SatCLIP checkpoint (e.g. satclip-vit16-l40.ckpt); the reference demands
+            it for every model name, also those that never read it.
         device: 'cuda' / 'cuda:N'.
         **kwargs: ``db_path`` (required) - the range_db_*.npz bank; ``beta`` (RANGE+, default 0.5).
     """

@@ -27,6 +27,13 @@ TEMP_RANGE = 15.0        # range/range.py:103
 TEMP_RANGE_PLUS = 12.0   # range/range.py:108
 TEMP_GEO = 40.0          # range/range.py:109
 
+# training-free coordinate encoders: load_model name -> (kernel mode, the reference's banner)
+_COORD_MODELS = {
+    "Direct": (_native.COORD_DIRECT, "Using Direct Encoding"),          # range.py:153-156
+    "Cartesian_3D": (_native.COORD_CARTESIAN3D, "Using Cartesian_3D"),   # range.py:159-162
+    "Wrap": (_native.COORD_WRAP, "Using Wrap"),                          # range.py:170-173
+}
+
 
 def _device_of(spec) -> torch.device:
     dev = torch.device(spec)
@@ -90,9 +97,18 @@ class LocationEncoder(nn.Module):
             self.encoder_params = enc
             self._device = _device_of(args.device)
             self.engine = make_engine(enc, None, self._device)
+        elif self.location_model_name in _COORD_MODELS:                 # range.py:152-162, 170-173
+            mode, banner = _COORD_MODELS[self.location_model_name]
+            print(banner)
+            self.location_feature_dim = _native.COORD_DIMS[mode]
+            self._model_id = None
+            self._coord_mode = mode
+            self._device = _device_of(args.device)
+            self.engine = _native.HipEngine(self._device)
         else:
-            # the reference dispatches 10 more encoder families here (range.py:124-200); they are
-            # unrelated baselines and out of scope for this engine
+            # the reference dispatches more encoder families here (GeoCLIP, CSP, SINR, TaxaBind,
+            # Theory, sphere2vec; range.py:124-198): third-party pretrained baselines, out of
+            # scope for this engine
             raise NotImplementedError(f"{self.location_model_name} not implemented")
         self.eval()
 
@@ -115,6 +131,15 @@ class LocationEncoder(nn.Module):
         (range.py:222/240).  ``return_device=True`` returns the device tensor instead (no D2H)."""
         x = self._coords(coords)
         B = x.shape[0]
+        if getattr(self, "_coord_mode", None) is not None:
+            # Direct / Wrap return a device tensor, Cartesian_3D a host ndarray (its rad_to_cart
+            # runs in numpy, range.py:265-268)
+            d = self.location_feature_dim
+            out = (self.engine.coord_features(x, self._coord_mode) if B else
+                   torch.empty((0, d), dtype=torch.float64, device=x.device))
+            if self._coord_mode == _native.COORD_CARTESIAN3D and not return_device:
+                return out.cpu().numpy()
+            return out
         if self._model_id is None:
             # plain SatCLIP: the un-normalised (B,256) float64 embedding, a device tensor like
             # the reference's (range.py:244-245)

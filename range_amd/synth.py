@@ -143,3 +143,70 @@ def make_queries(n: int, seed: int = 7, lat_max: float = 45.0, lat_min: float | 
         mag = rng.uniform(lat_min, lat_max, size=n)
         lat = mag * rng.choice([-1.0, 1.0], size=n)
     return np.stack([lon, lat], axis=1).astype(np.float64)
+
+
+# ---- downstream probe tasks (range/utils/evaluate.py reads '<task>_train.npz' / '<task>_val.npz'
+# with keys 'embeddings' and 'y', written by range/utils/save.py:38, :58) -------------------------
+def make_probe_task(kind: str, n_train: int, n_val: int, dim: int, seed: int, n_classes: int = 0,
+                    n_targets: int = 1, noise: float = 0.3,
+                    prior_scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seeded stand-in for saved embeddings + labels.  ``kind`` is 'regression' (float64 targets,
+    shape (n,) or (n,n_targets)) or 'classification' (int64 labels with a skewed class prior so
+    that some classes are rare).  Features have unequal scales and offsets and a low-rank
+    correlated part, like real embedding columns."""
+    rng = np.random.default_rng(seed)
+    n = n_train + n_val
+    rank = max(4, dim // 8)
+    basis = rng.standard_normal((rank, dim)) / math.sqrt(rank)
+    latent = rng.standard_normal((n, rank))
+    col_scale = np.exp(rng.uniform(-2.0, 1.0, size=dim))
+    col_shift = rng.uniform(-3.0, 3.0, size=dim)
+    X = (latent @ basis + 0.5 * rng.standard_normal((n, dim))) * col_scale + col_shift
+    if kind == "regression":
+        w = rng.standard_normal((rank, n_targets))
+        y = latent @ w + noise * math.sqrt(rank) * rng.standard_normal((n, n_targets)) + 5.0
+        y = y[:, 0] if n_targets == 1 else y
+    elif kind == "classification":
+        w = rng.standard_normal((rank, n_classes))
+        prior = prior_scale * np.log(rng.dirichlet(np.full(n_classes, 0.6)) + 1e-4)
+        score = latent @ w + noise * math.sqrt(rank) * rng.gumbel(size=(n, n_classes)) + prior
+        y = np.argmax(score, axis=1).astype(np.int64) * 3 + 7      # labels are not 0..C-1
+    else:
+        raise ValueError(kind)
+    return {"train_embeddings": X[:n_train], "train_y": y[:n_train],
+            "val_embeddings": X[n_train:], "val_y": y[n_train:]}
+
+
+def write_probe_task(embeddings_dir: str, model_name: str, task_name: str,
+                     task: Dict[str, np.ndarray]) -> Tuple[str, str]:
+    """Write the two npz files where evaluate_npz looks for them (evaluate.py:15-16)."""
+    d = os.path.join(embeddings_dir, model_name)
+    os.makedirs(d, exist_ok=True)
+    tr = os.path.join(d, f"{task_name}_train.npz")
+    va = os.path.join(d, f"{task_name}_val.npz")
+    np.savez(tr, embeddings=task["train_embeddings"], y=task["train_y"])
+    np.savez(va, embeddings=task["val_embeddings"], y=task["val_y"])
+    return tr, va
+
+
+#: probe cases shared by the golden generator, the oracle tests and the GPU parity tests:
+#: tag -> (task_name as the reference dispatches on it, make_probe_task kwargs)
+PROBE_CASES = {
+    "reg_d64": ("elevation", dict(kind="regression", n_train=500, n_val=200, dim=64, seed=101)),
+    "reg_d1280": ("population", dict(kind="regression", n_train=4000, n_val=1000, dim=1280,
+                                     seed=102)),
+    "reg_wide": ("temperature", dict(kind="regression", n_train=900, n_val=300, dim=1280,
+                                     seed=103)),
+    "reg_two_targets": ("nightlights", dict(kind="regression", n_train=1500, n_val=400, dim=256,
+                                            seed=104, n_targets=2)),
+    "cls_biome": ("biome", dict(kind="classification", n_train=3000, n_val=1000, dim=256,
+                                seed=105, n_classes=14)),
+    "cls_country": ("country", dict(kind="classification", n_train=5000, n_val=1200, dim=1280,
+                                    seed=106, n_classes=40)),
+    "cls_checker": ("checker_5", dict(kind="classification", n_train=1200, n_val=500, dim=128,
+                                      seed=107, n_classes=2)),
+    "cls_rare": ("ecoregion", dict(kind="classification", n_train=400, n_val=150, dim=96,
+                                   seed=109, n_classes=25, prior_scale=2.0)),
+    "cls_ocean": ("ocean", dict(kind="classification", n_train=2000, n_val=500, dim=1280,
+                                seed=108, n_classes=2)),
+}

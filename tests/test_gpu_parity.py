@@ -445,3 +445,31 @@ def test_encoder_edge_coordinates():
     np.testing.assert_allclose(e64.cpu().numpy(), ref, rtol=0, atol=5e-12)
     np.testing.assert_allclose(np.linalg.norm(e64.cpu().numpy(), axis=1), 1.0, atol=1e-12)
     np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1.2e-7)
+
+
+def test_coordinate_encoders_vs_reference_golden():
+    """load_model('Direct' | 'Cartesian_3D' | 'Wrap') against the reference's outputs
+    (tests/golden/coord_encoders.npz) and the oracle: same values, dims and return types."""
+    from range_amd import load_model
+    g = np.load(os.path.join(GOLDEN, "coord_encoders.npz"))
+    q = g["lonlat"]
+    for name, dim in (("Direct", 2), ("Cartesian_3D", 3), ("Wrap", 4)):
+        m = load_model(name, pretrained_path="unused", device="cuda:0")
+        assert m.location_feature_dim == dim == int(g[name + "_dim"])
+        out = m(torch.from_numpy(q).to("cuda:0"))
+        if str(g[name + "_type"]) == "ndarray":
+            assert isinstance(out, np.ndarray)
+            got = out
+        else:
+            assert torch.is_tensor(out) and out.is_cuda and out.dtype == torch.float64
+            got = out.cpu().numpy()
+        assert got.shape == (q.shape[0], dim)
+        # multiply/divide are exact; the device sin/cos may differ from libm in the last ulp
+        np.testing.assert_allclose(got, g[name], rtol=0, atol=(0 if name == "Direct" else 4e-16))
+        np.testing.assert_allclose(got, O.coord_features(q, name), rtol=0, atol=4e-16)
+        big = synth.make_queries(5000, seed=77, lat_max=89.99)
+        got = m(torch.from_numpy(big).to("cuda:0"))
+        got = got if isinstance(got, np.ndarray) else got.cpu().numpy()
+        np.testing.assert_allclose(got, O.coord_features(big, name), rtol=0, atol=4e-16)
+    with pytest.raises(ValueError):
+        load_model("Wrap")                                     # load_model.py:31-32 applies to all
