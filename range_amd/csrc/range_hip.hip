@@ -12,65 +12,12 @@
 #include <vector>
 
 #include "../../include/range_hip.h"
+#include "host_common.h"
 #include "attend_kernels.h"
 #include "encoder_kernel.h"
 
 using namespace range_hip;
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t e__ = (expr);                                                           \
-        if (e__ != hipSuccess)                                                             \
-            return fail(RANGE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                        __FILE__, __LINE__);                                               \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    hipError_t ensure(size_t count) {
-        if (count <= n) return hipSuccess;
-        if (p) {
-            // growth only happens between batches; make sure nothing still reads the old buffer
-            hipError_t e = hipDeviceSynchronize();
-            if (e != hipSuccess) return e;
-            (void)hipFree(p);
-            p = nullptr;
-            n = 0;
-        }
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    hipError_t upload(const std::vector<T>& h) {
-        hipError_t e = ensure(h.size());
-        if (e != hipSuccess) return e;
-        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-};
-
-}  // namespace
+using namespace range_host;
 
 struct range_ctx {
     int device = 0;
@@ -123,18 +70,6 @@ struct ProfScope {
 }  // namespace
 
 namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 // Number of bank splits.  Workgroups of both scan kernels are equal-cost, so the chip runs them
 // in near lock-step "rounds" of n_cu * wg_per_cu workgroups: pick the split count whose last

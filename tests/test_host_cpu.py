@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.range_abi_version() == 1
     assert lib.range_last_error() is not None
+    # the ridge-probe header, same library
+    from range_amd import _probe_native
+    header = open(os.path.join(REPO, "include", "range_probe.h")).read()
+    declared = set(re.findall(r"\b(range_probe_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_probe_native.SYMBOLS)
+    lib = _probe_native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_loader_errors_match_reference(tmp_path):

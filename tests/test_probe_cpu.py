@@ -93,3 +93,45 @@ def test_ridge_and_scaler_match_sklearn():
         pred = po.classifier_fit_predict(Xs[:200], labels[:200], Xs[200:], 1.0)
         ref = RidgeClassifier(alpha=1.0).fit(Xs[:200], labels[:200]).predict(Xs[200:])
         np.testing.assert_array_equal(pred, ref)
+
+
+def test_product_fold_assignment_matches_sklearn():
+    """The host-side fold logic of range_amd/evaluate.py (indices only, no arithmetic)."""
+    from sklearn.model_selection import KFold, StratifiedKFold
+    from range_amd import evaluate as ev
+    rng = np.random.default_rng(5)
+    for n, k in ((10, 3), (11, 3), (12, 3), (1000, 3), (7, 7), (29, 10)):
+        ids = ev.kfold_ids(n, k)
+        np.testing.assert_array_equal(ids, po.kfold_ids(n, k))
+        for f, (_, te) in enumerate(KFold(k).split(np.zeros(n))):
+            np.testing.assert_array_equal(np.nonzero(ids == f)[0], te)
+    for n, c, k in ((200, 3, 10), (503, 17, 10), (64, 2, 10), (300, 40, 10), (90, 5, 3)):
+        y = rng.choice(np.arange(c) * 5 - 3, size=n, p=rng.dirichlet(np.ones(c)))
+        ids = ev.stratified_kfold_ids(y, k)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for f, (_, te) in enumerate(StratifiedKFold(k).split(np.zeros(n), y)):
+                np.testing.assert_array_equal(np.nonzero(ids == f)[0], te)
+    with pytest.raises(ValueError):
+        ev.stratified_kfold_ids(np.array([0, 1, 2, 0, 1, 2]), 3 + 1)
+    assert ev._is_classification("checker_9") and not ev._is_classification("elevation")
+
+
+def test_probe_requires_gpu(tmp_path):
+    import torch
+    from argparse import Namespace
+    from range_amd import evaluate as ev
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    task_name, kw = synth.PROBE_CASES["reg_d64"]
+    synth.write_probe_task(str(tmp_path), "RANGE+", task_name, synth.make_probe_task(**kw))
+    args = Namespace(embeddings_dir=str(tmp_path), location_model_name="RANGE+", task_name=task_name)
+    with pytest.raises(RuntimeError):              # no CPU fallback: the loader fails loudly
+        ev.evaluate_npz(args)
+    with pytest.raises(AssertionError):            # evaluate.py:17-18
+        ev.evaluate_npz(Namespace(embeddings_dir=str(tmp_path), location_model_name="RANGE+",
+                                  task_name="missing"))
+    with pytest.raises(NotImplementedError):       # evaluate.py:31-32
+        synth.write_probe_task(str(tmp_path), "RANGE+", "inat_2018", synth.make_probe_task(**kw))
+        ev.evaluate_npz(Namespace(embeddings_dir=str(tmp_path), location_model_name="RANGE+",
+                                  task_name="inat_2018"))
