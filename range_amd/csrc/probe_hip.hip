@@ -34,8 +34,9 @@ int launch_gemm(range_probe_ctx* c, GemmArgs g, bool a_kc, bool b_kc, int batch,
     if (g.batch_inner <= 0) g.batch_inner = 1;
     int splits = 1;
     if (batch == 1 && g.K >= 2 * 512) {
-        const int slots = 2 * c->n_cu;                       // 2 workgroups per CU
-        splits = std::min(g.K / 512, std::max(1, cdiv(2 * slots, tiles)));
+        // two full rounds of the chip's 2 * n_cu workgroup slots, never a nearly empty third one
+        const int slots = 2 * c->n_cu;
+        splits = std::min(g.K / 512, std::max(1, 2 * slots / tiles));
     }
     g.k_chunk = cdiv(cdiv(g.K, splits), GEMM_KT) * GEMM_KT;
     splits = std::max(1, cdiv(g.K, g.k_chunk));
@@ -49,10 +50,10 @@ int launch_gemm(range_probe_ctx* c, GemmArgs g, bool a_kc, bool b_kc, int batch,
         g.c_ss = (int64_t)g.M * g.N;
     }
     const dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)batch);
-    if (a_kc && b_kc) hipLaunchKernelGGL((dgemm_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (a_kc) hipLaunchKernelGGL((dgemm_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (b_kc) hipLaunchKernelGGL((dgemm_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((dgemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (a_kc && b_kc) hipLaunchKernelGGL((dgemm_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, s, g);
+    else if (a_kc) hipLaunchKernelGGL((dgemm_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, s, g);
+    else if (b_kc) hipLaunchKernelGGL((dgemm_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, s, g);
+    else hipLaunchKernelGGL((dgemm_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, s, g);
     HIP_TRY(hipGetLastError());
     if (splits > 1) {
         const int64_t cnt = (int64_t)g.M * g.N;
@@ -246,7 +247,7 @@ int range_probe_solve(range_probe_ctx* c, const double* Gtot, const double* Btot
     // ---- factor: right-looking, 64-wide panels, all systems per launch -------------------
     for (int p0 = 0; p0 < d; p0 += PANEL) {
         const int nb = std::min(PANEL, d - p0);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(Q), dim3(256), 0, s, A, (int64_t)d, dd, p0, nb,
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(Q), dim3(64), 0, s, A, (int64_t)d, dd, p0, nb,
                            c->d_info.p);
         HIP_TRY(hipGetLastError());
         const int below = d - p0 - nb;
@@ -303,7 +304,7 @@ int range_probe_solve(range_probe_ctx* c, const double* Gtot, const double* Btot
         if (rc) return rc;
     }
     hipLaunchKernelGGL(intercept_kernel, dim3((unsigned)cdiv((int64_t)n_alpha * cc, 64), (unsigned)groups),
-                       dim3(64), 0, s, p, W, c0);
+                       dim3(64 * ICPT_SLICES), 0, s, p, W, c0);
     HIP_TRY(hipGetLastError());
 
     std::vector<int32_t> info(Q);

@@ -19,7 +19,7 @@ namespace range_probe {
 
 typedef double pd4 __attribute__((ext_vector_type(4)));
 
-constexpr int GEMM_TILE = 128;   // C tile per workgroup (4 waves, 64x64 each)
+constexpr int GEMM_TILE = 128;   // C tile per workgroup (8 waves, 32x64 each)
 constexpr int GEMM_KT = 16;      // K extent of one LDS stage (4 MFMA k-steps)
 constexpr int GEMM_LD = 130;     // LDS row stride in doubles (bank spread for both access patterns)
 constexpr int PANEL = 64;        // Cholesky panel width
@@ -128,8 +128,12 @@ struct GemmArgs {
 
 // A_KC / B_KC: the K index is the contiguous one of that operand (selects the coalesced
 // global -> LDS thread mapping; the strides above stay authoritative for addressing).
+// 8 waves per workgroup, each owning a 32 x 64 part of the tile (8 accumulators, <= 128 VGPRs):
+// two workgroups per CU = 4 waves per SIMD, which is what it takes to keep the float64 MFMA pipe
+// busy (tools/micro/mfma_f64_peak.hip: 36 TFLOP/s with 1-2 waves per SIMD, 47-49 with >= 3).
+constexpr int GEMM_THREADS = 512;
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void dgemm_kernel(GemmArgs g) {
     __shared__ double As[GEMM_KT * GEMM_LD];
     __shared__ double Bs[GEMM_KT * GEMM_LD];
 
@@ -155,22 +159,22 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 64;
     const int r = lane & 15, q = lane >> 4;
 
-    // global -> register staging: 8 doubles of A and 8 of B per thread and stage
-    int a_m[8], a_k[8], b_n[8], b_k[8];
+    // global -> register staging: 4 doubles of A and 4 of B per thread and stage
+    int a_m[4], a_k[4], b_n[4], b_k[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (A_KC) { a_k[j] = t & 15; a_m[j] = (t >> 4) + 16 * j; }
-        else      { a_m[j] = t & 127; a_k[j] = (t >> 7) + 2 * j; }
-        if (B_KC) { b_k[j] = t & 15; b_n[j] = (t >> 4) + 16 * j; }
-        else      { b_n[j] = t & 127; b_k[j] = (t >> 7) + 2 * j; }
+    for (int j = 0; j < 4; ++j) {
+        if (A_KC) { a_k[j] = t & 15; a_m[j] = (t >> 4) + 32 * j; }
+        else      { a_m[j] = t & 127; a_k[j] = (t >> 7) + 4 * j; }
+        if (B_KC) { b_k[j] = t & 15; b_n[j] = (t >> 4) + 32 * j; }
+        else      { b_n[j] = t & 127; b_k[j] = (t >> 7) + 4 * j; }
     }
-    double ra[8], rb[8];
+    double ra[4], rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int m = m0 + a_m[j], ka = k0 + a_k[j];
             ra[j] = (m < g.M && ka < kend) ? A[(int64_t)m * g.a_rs + (int64_t)ka * g.a_cs] : 0.0;
             const int n = n0 + b_n[j], kb = k0 + b_k[j];
@@ -178,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
         }
     };
 
-    pd4 acc[4][4];
+    pd4 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = pd4{0.0, 0.0, 0.0, 0.0};
 
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_KT) {
         __syncthreads();                       // the previous stage's operand reads are done
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             As[a_k[j] * GEMM_LD + a_m[j]] = ra[j];
             Bs[b_k[j] * GEMM_LD + b_n[j]] = rb[j];
         }
@@ -197,14 +201,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < GEMM_KT / 4; ++ks) {
             const int kk = (ks * 4 + q) * GEMM_LD;
-            double a[4], b[4];
+            double a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = As[kk + wm + i * 16 + r];
-                b[i] = Bs[kk + wn + i * 16 + r];
-            }
+            for (int i = 0; i < 2; ++i) a[i] = As[kk + wm + i * 16 + r];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk + wn + j * 16 + r];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -213,12 +216,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 
     const bool slab = gridDim.y > 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = m0 + wm + i * 16 + q + 4 * e;   // f64 16x16x4 D layout: row = lane/16 + 4*reg
+                // f64 16x16x4 accumulator layout: row = lane/16 + 4*reg, column = lane%16
+                const int row = m0 + wm + i * 16 + q + 4 * e;
                 const int col = n0 + wn + j * 16 + r;
                 if (row < g.M && col < g.N) {
                     double* p = C + (int64_t)row * g.ldc + col;
@@ -296,83 +300,145 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs p) {
     }
 }
 
-// Diagonal block of the blocked Cholesky: factor A[p0:p0+nb, p0:p0+nb] (lower) in LDS.
-// One workgroup per system (blockIdx.x); info[system] = first non-positive pivot (1-based) or 0.
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Aall, int64_t ld,
-                                                         int64_t sys_stride, int32_t p0, int32_t nb,
-                                                         int32_t* __restrict__ info) {
-    __shared__ double L[PANEL][PANEL + 1];
-    double* a = Aall + (int64_t)blockIdx.x * sys_stride + (int64_t)p0 * ld + p0;
-    const int t = threadIdx.x;
-    for (int e = t; e < PANEL * PANEL; e += 256) {
+// ---- 64-wide panel kernels ------------------------------------------------------------------
+// All three keep one 64-vector per thread in registers (static indices, fully unrolled) and sweep
+// it once: element j is finalised, then the remaining elements receive its rank-1 update - 2016
+// independent FMAs per thread and no dependent chain longer than the 64 pivots.  The triangular
+// factor comes from LDS as broadcast reads.
+
+// Load the factored diagonal block L11 (nb x nb, lower) into LDS, padded to 64 x 64 with the
+// identity so that a short last panel needs no special case.
+__device__ __forceinline__ void load_l11(double (*L)[PANEL + 2], const double* __restrict__ l11,
+                                         int64_t ld, int nb, int t, int nthreads) {
+    for (int e = t; e < PANEL * PANEL; e += nthreads) {
         const int i = e >> 6, j = e & 63;
-        L[i][j] = (i < nb && j <= i) ? a[(int64_t)i * ld + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        double djj = L[j][j];
-        if (!(djj > 0.0)) {
-            if (t == 0 && info[blockIdx.x] == 0) info[blockIdx.x] = p0 + j + 1;
-            djj = 1.0;
-        }
-        const double piv = sqrt(djj);
-        __syncthreads();
-        if (t == j) L[j][j] = piv;
-        else if (t > j && t < PANEL) L[t][j] = L[t][j] / piv;
-        __syncthreads();
-        for (int e = t; e < PANEL * PANEL; e += 256) {
-            const int i = e >> 6, k = e & 63;
-            if (k > j && i >= k) L[i][k] -= L[i][j] * L[k][j];
-        }
-        __syncthreads();
-    }
-    for (int e = t; e < PANEL * PANEL; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        if (i < nb && j <= i) a[(int64_t)i * ld + j] = L[i][j];
+        L[i][j] = (i < nb && j <= i) ? l11[(int64_t)i * ld + j] : (i == j ? 1.0 : 0.0);
     }
 }
 
-// Panel below the diagonal block: rows i >= p0+nb, X[i, :] = A[i, p0:p0+nb] * L11^-T.
-// One wave per 64 rows (blockIdx.x), one thread per row; blockIdx.y = system.
+// Triangular solve of one 64-vector per thread.  The vector lives in a lane-private LDS column
+// X[k*XS + t] (XS = 65: conflict-free both for the thread's own accesses and for the transposed
+// staging of row tiles); it is swept in 8 blocks of 8: the block's 8 unknowns are finalised in
+// registers, then every remaining element receives their rank-8 update (8 independent-of-x FMAs
+// per element, L11 entries as LDS broadcast reads).  Real loops over the blocks keep live ranges
+// short - the fully unrolled register formulation makes hipcc hoist or sink 2016 operands and
+// spill them.
+// FWD:  x <- L^-1 x  (also x <- x L^-T for a row vector);  BWD:  x <- L^-T x.
+constexpr int XS = PANEL + 1;
+template <bool BWD>
+__device__ __forceinline__ void tri_solve64(double* __restrict__ X, int t,
+                                            const double (*L)[PANEL + 2]) {
+    if (!BWD) {
+        for (int jb = 0; jb < PANEL; jb += 8) {
+            double xb[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) xb[a] = X[(jb + a) * XS + t];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                xb[a] = xb[a] / L[jb + a][jb + a];
+#pragma unroll
+                for (int b = a + 1; b < 8; ++b) xb[b] -= L[jb + b][jb + a] * xb[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) X[(jb + a) * XS + t] = xb[a];
+#pragma unroll 4
+            for (int m = jb + 8; m < PANEL; ++m) {
+                double v = X[m * XS + t];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) v -= L[m][jb + a] * xb[a];
+                X[m * XS + t] = v;
+            }
+        }
+    } else {
+        for (int jb = PANEL - 8; jb >= 0; jb -= 8) {
+            double xb[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) xb[a] = X[(jb + a) * XS + t];
+#pragma unroll
+            for (int a = 7; a >= 0; --a) {
+                xb[a] = xb[a] / L[jb + a][jb + a];
+#pragma unroll
+                for (int b = 0; b < a; ++b) xb[b] -= L[jb + a][jb + b] * xb[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) X[(jb + a) * XS + t] = xb[a];
+#pragma unroll 4
+            for (int m = 0; m < jb; ++m) {
+                double v = X[m * XS + t];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) v -= L[jb + a][m] * xb[a];
+                X[m * XS + t] = v;
+            }
+        }
+    }
+}
+
+// Diagonal block of the blocked Cholesky: factor A[p0:p0+nb, p0:p0+nb] (lower) in place.
+// One wave per system (blockIdx.x), lane t owns row t; the pivot column travels through LDS.
+// info[system] = first non-positive pivot (1-based) or 0.
+__global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Aall, int64_t ld,
+                                                        int64_t sys_stride, int32_t p0, int32_t nb,
+                                                        int32_t* __restrict__ info) {
+    __shared__ double col[PANEL];
+    double* a = Aall + (int64_t)blockIdx.x * sys_stride + (int64_t)p0 * ld + p0;
+    const int t = threadIdx.x;
+    const int tr = t < nb ? t : nb - 1;               // clamped row for the loads
+    double x[PANEL];
+#pragma unroll
+    for (int j = 0; j < PANEL; ++j) {
+        const double v = a[(int64_t)tr * ld + (j < nb ? j : nb - 1)];
+        x[j] = (t < nb && j <= t) ? v : (j == t ? 1.0 : 0.0);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < PANEL; ++j) {
+        double djj = __shfl(x[j], j);                 // lane j holds the diagonal element
+        if (!(djj > 0.0)) { if (bad == 0) bad = p0 + j + 1; djj = 1.0; }
+        const double piv = sqrt(djj);
+        x[j] = t == j ? piv : x[j] / piv;
+        __syncthreads();                              // (one wave) previous column fully consumed
+        col[t] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int m = j + 1; m < PANEL; ++m) x[m] -= x[j] * col[m];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t == 0 && bad && info[blockIdx.x] == 0) info[blockIdx.x] = bad;
+#pragma unroll
+    for (int j = 0; j < PANEL; ++j)
+        if (t < nb && j <= t) a[(int64_t)t * ld + j] = x[j];
+}
+
+// Panel below the diagonal block: rows i >= p0+nb, A[i, p0:p0+nb] <- A[i, p0:p0+nb] * L11^-T.
+// One wave per 64 rows (blockIdx.x), one thread per row; the 64 x 64 tile is read and written
+// coalesced (lane = column) and transposed through LDS; blockIdx.y = system.
 __global__ __launch_bounds__(64) void trsm_rows_kernel(double* __restrict__ Aall, int64_t ld,
                                                        int64_t sys_stride, int32_t p0, int32_t nb,
                                                        int32_t d) {
     __shared__ double L[PANEL][PANEL + 2];
-    __shared__ double R[PANEL][PANEL + 1];
+    __shared__ double X[PANEL * XS];
     double* base = Aall + (int64_t)blockIdx.y * sys_stride;
-    const double* l11 = base + (int64_t)p0 * ld + p0;
-    const int row0 = p0 + nb + blockIdx.x * 64;
     const int t = threadIdx.x;
-    for (int e = t; e < PANEL * PANEL; e += 64) {
-        const int i = e >> 6, j = e & 63;
-        L[i][j] = (i < nb && j <= i) ? l11[(int64_t)i * ld + j] : (i == j ? 1.0 : 0.0);
+    load_l11(L, base + (int64_t)p0 * ld + p0, ld, nb, t, 64);
+    const int row0 = p0 + nb + blockIdx.x * 64;
+#pragma unroll 8
+    for (int i = 0; i < PANEL; ++i) {           // row i of the tile: element t -> X[t][i]
         const int row = row0 + i;
-        R[i][j] = (row < d && j < nb) ? base[(int64_t)row * ld + p0 + j] : 0.0;
+        X[t * XS + i] = (row < d && t < nb) ? base[(int64_t)row * ld + p0 + t] : 0.0;
     }
     __syncthreads();
-    double x[PANEL];
-#pragma unroll
-    for (int j = 0; j < PANEL; ++j) {
-        double s = R[t][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= x[k] * L[j][k];
-        x[j] = s / L[j][j];
-        __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads of later rows from piling up
-    }
-#pragma unroll
-    for (int j = 0; j < PANEL; ++j) R[t][j] = x[j];
+    tri_solve64<false>(X, t, L);
     __syncthreads();
-    for (int e = t; e < PANEL * PANEL; e += 64) {
-        const int i = e >> 6, j = e & 63;
+#pragma unroll 8
+    for (int i = 0; i < PANEL; ++i) {
         const int row = row0 + i;
-        if (row < d && j < nb) base[(int64_t)row * ld + p0 + j] = R[i][j];
+        if (row < d && t < nb) base[(int64_t)row * ld + p0 + t] = X[t * XS + i];
     }
 }
 
 // Triangular solve of one 64-row block of right-hand sides with the factored diagonal block:
 // forward (TRANS = false):  Y = L11^-1 * R ;  backward (TRANS = true):  X = L11^-T * Y.
-// One thread per RHS column (blockIdx.x * 64 + lane), its 64 unknowns in a private LDS column
-// (lane-contiguous, conflict-free; the L11 element is a broadcast read); blockIdx.y = system.
+// One thread per RHS column (blockIdx.x * 64 + lane); blockIdx.y = system (group, alpha).
 template <bool TRANS>
 __global__ __launch_bounds__(64) void trsv_cols_kernel(const double* __restrict__ Aall, int64_t ld,
                                                        int64_t sys_stride, int32_t p0, int32_t nb,
@@ -380,55 +446,51 @@ __global__ __launch_bounds__(64) void trsv_cols_kernel(const double* __restrict_
                                                        int32_t n_alpha, int64_t r_grp_stride,
                                                        int64_t r_alpha_stride, int32_t c) {
     __shared__ double L[PANEL][PANEL + 2];
-    __shared__ double X[PANEL][64];
+    __shared__ double X[PANEL * XS];
     const int sys = blockIdx.y;
-    const double* l11 = Aall + (int64_t)sys * sys_stride + (int64_t)p0 * ld + p0;
     const int t = threadIdx.x;
-    for (int e = t; e < PANEL * PANEL; e += 64) {
-        const int i = e >> 6, j = e & 63;
-        L[i][j] = (i < nb && j <= i) ? l11[(int64_t)i * ld + j] : (i == j ? 1.0 : 0.0);
-    }
+    load_l11(L, Aall + (int64_t)sys * sys_stride + (int64_t)p0 * ld + p0, ld, nb, t, 64);
     const int col = blockIdx.x * 64 + t;
     const bool active = col < c;
     double* rhs = Rall + (sys / n_alpha) * r_grp_stride + (sys % n_alpha) * r_alpha_stride +
                   (int64_t)p0 * ldr + (active ? col : 0);
-    for (int k = 0; k < nb; ++k) X[k][t] = active ? rhs[(int64_t)k * ldr] : 0.0;
+#pragma unroll 8
+    for (int k = 0; k < PANEL; ++k)
+        X[k * XS + t] = (active && k < nb) ? rhs[(int64_t)k * ldr] : 0.0;
     __syncthreads();
-    if (!TRANS) {
-        for (int k = 0; k < nb; ++k) {
-            double s = X[k][t];
-            for (int m = 0; m < k; ++m) s -= L[k][m] * X[m][t];
-            X[k][t] = s / L[k][k];
-        }
-    } else {
-        for (int k = nb - 1; k >= 0; --k) {
-            double s = X[k][t];
-            for (int m = k + 1; m < nb; ++m) s -= L[m][k] * X[m][t];
-            X[k][t] = s / L[k][k];
-        }
-    }
+    tri_solve64<TRANS>(X, t, L);
     if (active)
-        for (int k = 0; k < nb; ++k) rhs[(int64_t)k * ldr] = X[k][t];
+        for (int k = 0; k < nb; ++k) rhs[(int64_t)k * ldr] = X[k * XS + t];
 }
 
-// intercept in Z coordinates: c0[g][a][k] = tau_k - sum_i delta_i W[g][i][a][k]
-__global__ __launch_bounds__(64) void intercept_kernel(AssembleArgs p, const double* __restrict__ W,
-                                                       double* __restrict__ c0) {
+// intercept in Z coordinates: c0[g][a][k] = tau_k - sum_i delta_i W[g][i][a][k].
+// Block = 64 (alpha, target) columns x 16 slices of the feature index, reduced through LDS.
+constexpr int ICPT_SLICES = 16;
+__global__ __launch_bounds__(64 * ICPT_SLICES) void intercept_kernel(AssembleArgs p,
+                                                                     const double* __restrict__ W,
+                                                                     double* __restrict__ c0) {
+    __shared__ double part[ICPT_SLICES][64];
     const int grp = blockIdx.y;
     const int ac = p.n_alpha * p.c;
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= ac) return;
-    const int k = e % p.c;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     const double ntr = p.ntr[grp];
     double s = 0.0;
-    for (int i = 0; i < p.d; ++i) {
-        double si = p.stot[i];
-        if (p.sf) si -= p.sf[(int64_t)grp * p.d + i];
-        s += (si / ntr) * W[((int64_t)grp * p.d + i) * ac + e];
+    if (e < ac)
+        for (int i = slice; i < p.d; i += ICPT_SLICES) {
+            double si = p.stot[i];
+            if (p.sf) si -= p.sf[(int64_t)grp * p.d + i];
+            s += (si / ntr) * W[((int64_t)grp * p.d + i) * ac + e];
+        }
+    part[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && e < ac) {
+        for (int k = 1; k < ICPT_SLICES; ++k) s += part[k][lane];
+        const int k = e % p.c;
+        double tk = p.ttot[k];
+        if (p.tf) tk -= p.tf[(int64_t)grp * p.c + k];
+        c0[(int64_t)grp * ac + e] = tk / ntr - s;
     }
-    double tk = p.ttot[k];
-    if (p.tf) tk -= p.tf[(int64_t)grp * p.c + k];
-    c0[(int64_t)grp * ac + e] = tk / ntr - s;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -60,11 +60,14 @@ def stratified_kfold_ids(y: np.ndarray, k: int) -> np.ndarray:
     sizes = np.bincount(cls, minlength=labels.size)
     if np.all(k > sizes):
         raise ValueError(f"n_splits={k} cannot be greater than the number of members in each class.")
+    n, n_cls = cls.shape[0], labels.size
     in_class_order = np.sort(cls)
-    ids = np.empty(cls.shape[0], dtype=np.int64)
-    for c in range(labels.size):
-        quota = np.array([np.count_nonzero(in_class_order[f::k] == c) for f in range(k)])
-        ids[cls == c] = np.repeat(np.arange(k), quota)
+    # quota[f, c] = rows of class c among positions f, f+k, f+2k, ... of the class-sorted sequence
+    quota = np.bincount((np.arange(n) % k) * n_cls + in_class_order,
+                        minlength=k * n_cls).reshape(k, n_cls)
+    ids = np.empty(n, dtype=np.int64)
+    by_class = np.argsort(cls, kind="stable")          # rows of class 0 in order, then class 1, ...
+    ids[by_class] = np.repeat(np.tile(np.arange(k), n_cls), quota.T.reshape(-1))
     return ids
 
 
@@ -85,9 +88,19 @@ class RidgeProbe:
         return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(self.device).contiguous()
 
     def fit_score(self, train_X, train_y, val_X, val_y, classification: bool,
-                  cv: Optional[int] = None) -> Dict[str, object]:
-        """Returns {'score': validation score, 'alpha': chosen alpha, 'cv_scores': (alphas, folds)}."""
+                  cv: Optional[int] = None, timings: Optional[dict] = None) -> Dict[str, object]:
+        """Returns {'score': validation score, 'alpha': chosen alpha, 'cv_scores': (alphas, folds)}.
+        ``timings`` (a dict) receives wall-clock seconds per stage, synchronising after each."""
+        import time
         eng = self.engine
+        t_last = [time.perf_counter()]
+
+        def lap(name):
+            if timings is not None:
+                torch.cuda.synchronize(self.device)
+                now = time.perf_counter()
+                timings[name] = timings.get(name, 0.0) + now - t_last[0]
+                t_last[0] = now
         A = len(self.alphas)
         train_y = np.asarray(train_y)
         val_y = np.asarray(val_y)
@@ -98,6 +111,7 @@ class RidgeProbe:
             raise ValueError("inconsistent shapes of embeddings / labels")
         if cv is None:
             cv = 10 if classification else 3                         # evaluate.py:30, :35
+        lap("h2d")
 
         # MinMaxScaler.fit: per-column range on the device, the d-vector bookkeeping on the host
         mn, mx, sm = (t.cpu().numpy() for t in eng.colstats(Xtr))
@@ -123,6 +137,7 @@ class RidgeProbe:
         edges = np.concatenate([[0], np.cumsum(sizes)])
         Z = eng.scale_rows(Xtr, self._dev(perm, torch.int64), scale_d, offset_d, shift_d)
         del Xtr
+        lap("scale_and_folds")
 
         # targets.  Classification: the -1/+1 indicator columns as they are (the decision rule
         # compares scores in those units, and the solver handles any origin through the column
@@ -138,9 +153,12 @@ class RidgeProbe:
             ybar = Y.mean(axis=0)
             T = self._dev((Y - ybar)[perm], torch.float64)
 
-        # one pass over the data: per-fold sufficient statistics
-        Gf, Bf = eng.empty((cv, d, d)), eng.empty((cv, d, c))
-        zsumf, tsumf = eng.empty((cv, d)), eng.empty((cv, c))
+        # one pass over the data: per-fold sufficient statistics.  Slot cv stays zero: "all rows
+        # minus nothing" is the refit on the whole training set, solved in the same batch.
+        Gf, Bf = eng.empty((cv + 1, d, d)), eng.empty((cv + 1, d, c))
+        zsumf, tsumf = eng.empty((cv + 1, d)), eng.empty((cv + 1, c))
+        for t_ in (Gf, Bf, zsumf, tsumf):
+            t_[cv].zero_()
         for f in range(cv):
             if sizes[f] == 0:
                 raise ValueError(f"fold {f} is empty")
@@ -148,11 +166,13 @@ class RidgeProbe:
             eng.gram(Z[r0:r1], T[r0:r1], Gf[f], Bf[f], zsumf[f], tsumf[f])
         Gtot, Btot = eng.sum_parts(Gf), eng.sum_parts(Bf)
         zsum, tsum = eng.sum_parts(zsumf), eng.sum_parts(tsumf)
+        lap("targets_and_gram")
 
-        # every (fold, alpha) fit, and the refit on all rows for every alpha
-        W, c0 = eng.solve(Gtot, Btot, zsum, tsum, [float(n - s) for s in sizes], self.alphas,
-                          Gf, Bf, zsumf, tsumf)
-        W_all, c0_all = eng.solve(Gtot, Btot, zsum, tsum, [float(n)], self.alphas)
+        # every (fold, alpha) fit and the refit on all rows for every alpha: one batched solve
+        W, c0 = eng.solve(Gtot, Btot, zsum, tsum, [float(n - s) for s in sizes] + [float(n)],
+                          self.alphas, Gf, Bf, zsumf, tsumf)
+        W_all, c0_all = W[cv:cv + 1], c0[cv:cv + 1]
+        lap("solve")
 
         # held-out scores
         cv_scores = np.empty((A, cv))
@@ -168,6 +188,7 @@ class RidgeProbe:
                 s = eng.r2_sums(P, c0[f], T[r0:r1], tsumf[f], A).cpu().numpy()
                 cv_scores[:, f] = np.mean(1.0 - s[:, :, 0] / s[:, :, 1], axis=1)
         best = int(np.argmax(cv_scores.mean(axis=1)))                # first maximum wins
+        lap("fold_scores")
 
         # validation score of the refit
         Zv = eng.scale_rows(Xv, None, scale_d, offset_d, shift_d)
@@ -185,6 +206,7 @@ class RidgeProbe:
             _, _, tv_sum = eng.colstats(Tv)
             s = eng.r2_sums(Pv, c0_all[0], Tv, tv_sum, A).cpu().numpy()
             score = float(np.mean(1.0 - s[best, :, 0] / s[best, :, 1]))
+        lap("validation")
         return {"score": score, "alpha": self.alphas[best], "cv_scores": cv_scores}
 
 
