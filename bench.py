@@ -31,7 +31,8 @@ sys.path.insert(0, REPO)
 from range_amd import _native, synth          # noqa: E402
 from range_amd.bank import prepare_bank       # noqa: E402
 
-FLOP_PAIR_ATTEND = 2 * (256 + 3 + 1024)       # pass 2, per (query, bank row): logits + w @ V
+FLOP_PAIR_ATTEND = 2 * (256 + 3 + 1024)       # pass 2 recomputing the logits, per (query, bank row)
+FLOP_PAIR_ATTEND_KEPT = 2 * (3 + 1024)        # pass 2 on the logits pass 1 kept: geo tile + w @ V
 FLOP_PAIR_STATS = 2 * (256 + 3)               # pass 1
 FLOP_PAIR_REFERENCE = 4614                    # the reference's arithmetic
 BANK_ROW_BYTES = (256 + 1024 + 3) * 4         # 5132 B
@@ -53,7 +54,7 @@ def parse():
                          "(rehearsal of the N>1 code path on a 1-GPU box)")
     ap.add_argument("--shard-chunks", type=int, default=0,
                     help="query chunks of the sharded forward (0 = library default: 4 when N>1)")
-    ap.add_argument("--cpu-sample", type=int, default=2048,
+    ap.add_argument("--cpu-sample", type=int, default=6144,
                     help="queries of the same workload timed on the host for cpu_baseline (0=off)")
     return ap.parse_args()
 
@@ -161,13 +162,23 @@ def main():
         launches_per_step = att_n // a.steps
         q_per_launch = B * world // launches_per_step  # every rank attends all queries (in chunks)
         att_avg_ms = att_ms / att_n
-        flops = q_per_launch * n_local * FLOP_PAIR_ATTEND
+        # which pass 2 ran: on the logits kept by pass 1 (the default) or recomputing them
+        kept = eng.kept_queries() > 0
+        flops = q_per_launch * n_local * (FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND)
         achieved = flops / (att_avg_ms * 1e-3) / 1e12
+        # algorithmic bytes of one launch: the bank columns it reads once, per-query operands and
+        # output, and (kept variant) 4 B per (query, row) of logits read back
+        if kept:
+            alg_bytes = n_local * (1024 + 4) * 4 + q_per_launch * (32 + 4096) + q_per_launch * n_local * 4
+        else:
+            alg_bytes = n_local * BANK_ROW_BYTES + q_per_launch * (1040 + 4096)
         traffic = None
         pmc = os.path.join(REPO, "profiles", "attend_pmc.json")
         if not sharded and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                if ("stored" in j.get("kernel", "")) == kept:
+                    traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         qt, ns = eng.last_geometry()
@@ -186,14 +197,15 @@ def main():
                        "bank_rows": N, "queries_per_gpu": B, "hidden": H,
                        "bank_layout": "single GPU" if not sharded else f"row-sharded x{world}",
                        "query_tiles": qt, "bank_splits": ns},
-            "roofline": {"kernel": "attend_kernel<GEO> (pass 2: logits + w@V, f32 MFMA)",
+            "roofline": {"kernel": ("attend_stored_kernel<GEO> (pass 2 on kept logits: w@V, f32 MFMA)"
+                                    if kept else
+                                    "attend_kernel<GEO> (pass 2: logits + w@V, f32 MFMA)"),
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": traffic,
                          "avg_launch_ms": att_avg_ms, "launches": att_n,
                          "flop_per_launch": flops,
-                         "algorithmic_bytes_per_launch": n_local * BANK_ROW_BYTES
-                                                         + q_per_launch * (1040 + 4096)},
+                         "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_ms_per_step": {"encoder": en_ms / a.steps, "scan_stats": st_ms / a.steps,
                                     "attend": att_ms / a.steps},
             "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / (dt / a.steps) / 1e12,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 1
+#define RANGE_ABI_VERSION 2
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -117,10 +117,18 @@ int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev,
  *               range_merge_stats.
  *   topk : 0, or k in [1,16]: also emit the k largest semantic similarities of each query
  *          (the "brute-force top-k" side channel), descending, ties -> lower row index:
- *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local) */
+ *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local)
+ *   keep_logits : non-zero (with topk == 0): also keep the raw semantic dot products of this call
+ *          in the context (4 bytes per (query, bank row) of workspace) for range_attend_kept.  They
+ *          stay valid until the next range_scan_stats / range_set_bank on this ctx.  Silently not
+ *          kept when they would take more than half of the free device memory. */
 int range_scan_stats(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
                      float tau_sem, float tau_geo, float* stats_dev, int topk,
-                     float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
+                     float* topk_val_dev, int64_t* topk_idx_dev, int32_t keep_logits,
+                     range_stream_t stream);
+
+/* Number of queries whose logits the last range_scan_stats kept (0: none). */
+int64_t range_kept_queries(const range_ctx* ctx);
 
 /* Small-batch top-k, the HBM-streaming form of the keys scan (no reference counterpart; north star:
  * "brute-force cosine-similarity top-k ... coalesced HBM-streaming kernel with per-wavefront
@@ -148,6 +156,17 @@ int range_merge_topk(range_ctx* ctx, const float* val_parts_dev, const int64_t* 
 int range_attend(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
                  float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
                  float* partial_dev, range_stream_t stream);
+
+/* Kernel B, pass 2 on the logits KEPT by the last range_scan_stats(keep_logits = 1) of this ctx:
+ * same result as range_attend, bit for bit, for the queries [first_query, first_query + B) of
+ * that scan, without recomputing e . K^T (a fifth of pass 2's MFMA work; the kernel is MFMA-bound
+ * and reads the kept tiles back at 4 bytes per (query, row)).  first_query must be a multiple of
+ * 64; xq32_dev / stats_global_dev / partial_dev are those B queries' rows.  tau_sem, tau_geo and
+ * beta are free (the kept values are un-scaled): one scan serves several attends (beta sweeps).
+ * RANGE_ERR_STATE when nothing is kept. */
+int range_attend_kept(range_ctx* ctx, int64_t first_query, const float* xq32_dev, int64_t B,
+                      float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
+                      float* partial_dev, range_stream_t stream);
 
 /* The blend of range/range.py:238 on its own, with the reference's float32 rounding:
  * out = (1-beta)*G + beta*H over (B,1024) float32.  For beta sweeps: G = range_attend(beta=0),

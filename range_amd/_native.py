@@ -31,7 +31,7 @@ SYMBOLS = (
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
-    "range_coord_features",
+    "range_coord_features", "range_attend_kept", "range_kept_queries",
 )
 
 
@@ -69,7 +69,10 @@ def load_library() -> C.CDLL:
     lib.range_bank_rows.argtypes = [vp]
     lib.range_bank_rows.restype = i64
     lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
-    lib.range_scan_stats.argtypes = [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp, vp, vp]
+    lib.range_scan_stats.argtypes = [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp, vp, i32, vp]
+    lib.range_attend_kept.argtypes = [vp, i64, vp, i64, f32, f32, f32, vp, vp, vp]
+    lib.range_kept_queries.argtypes = [vp]
+    lib.range_kept_queries.restype = i64
     lib.range_merge_stats.argtypes = [vp, vp, i32, i64, vp, vp]
     lib.range_merge_topk.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp]
     lib.range_attend.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, vp]
@@ -85,7 +88,7 @@ def load_library() -> C.CDLL:
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 1:
+    if lib.range_abi_version() != 2:
         raise RangeNativeError("librange_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -217,7 +220,9 @@ class HipEngine:
         return out
 
     def scan_stats(self, e32: torch.Tensor, xq: torch.Tensor, tau_sem: float, tau_geo: float,
-                   topk: int = 0):
+                   topk: int = 0, keep_logits: bool = False):
+        """Pass 1.  ``keep_logits``: keep the raw semantic logits of this call in the context for
+        ``attend_kept`` (see ``kept_queries``)."""
         self._t(e32, torch.float32, (KEY_DIM,))
         self._t(xq, torch.float32, (4,))
         B = e32.shape[0]
@@ -228,8 +233,28 @@ class HipEngine:
             ti = self._empty((B, topk), torch.int64)
         _check(self.lib, self.lib.range_scan_stats(self._h, e32.data_ptr(), xq.data_ptr(), B,
                                                    tau_sem, tau_geo, stats.data_ptr(), topk,
-                                                   _ptr(tv), _ptr(ti), self._stream()))
+                                                   _ptr(tv), _ptr(ti), int(bool(keep_logits)),
+                                                   self._stream()))
         return (stats, tv, ti) if topk else stats
+
+    def kept_queries(self) -> int:
+        """Queries whose logits the last scan_stats(keep_logits=True) kept (0: none)."""
+        return int(self.lib.range_kept_queries(self._h))
+
+    def attend_kept(self, first_query: int, xq: torch.Tensor, tau_sem: float, tau_geo: float,
+                    beta: float, stats: torch.Tensor) -> torch.Tensor:
+        """Pass 2 for queries [first_query, first_query + len(xq)) of the last kept scan, from the
+        kept logits (bit-identical to ``attend``)."""
+        self._t(xq, torch.float32, (4,))
+        self._t(stats, torch.float32, (4,))
+        B = xq.shape[0]
+        if stats.shape[0] != B:
+            raise ValueError("xq and stats must have the same number of rows")
+        out = self._empty((B, VAL_DIM), torch.float32)
+        _check(self.lib, self.lib.range_attend_kept(self._h, first_query, xq.data_ptr(), B, tau_sem,
+                                                    tau_geo, beta, stats.data_ptr(), out.data_ptr(),
+                                                    self._stream()))
+        return out
 
     def topk_stream(self, e32: torch.Tensor, k: int):
         """Small-batch top-k by the HBM-streaming kernel (see range_hip.h)."""

@@ -69,7 +69,17 @@ struct ScanArgs {
     float k_geo;           // tau_geo * log2(e)
     float beta;
     unsigned long long* diag;   // diagnostic build only: per (workgroup, wave) cycle sums
+    // kept logits: the raw semantic dot products of pass 1, one 1 KB tile per (query tile, bank
+    // block, wave) in accumulator-register order (lane-linear float4).  Pass 1 writes them when
+    // non-null; attend_stored_kernel reads them instead of recomputing K . Q^T.
+    float* logits;
+    int32_t qt_offset;          // pass 2 on a sub-range of the scanned queries: first query / 64
 };
+
+// float offset of the kept-logit tile of (query tile, bank block, wave)
+__device__ __forceinline__ int64_t logit_tile(int64_t qtile, int32_t n_blocks, int block, int wave) {
+    return ((qtile * n_blocks + block) * 4 + wave) * 256;
+}
 
 // blockIdx -> (split, query tile).  Work items are numbered split-major (item = split * n_qtiles +
 // tile).  Blocks b and b+8 share an XCD (measured: XCC_ID == blockIdx % 8), so the blocks of XCD x
@@ -382,6 +392,8 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
         c.fence();
         const f32x4 ss = {c.sem(0), c.sem(1), c.sem(2), c.sem(3)};
         const f32x4 sg = c.g;
+        if (a.logits)   // keep the tile for pass 2 (the barrier's vmcnt(0) also covers this store)
+            *reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
         const int64_t row0 = (int64_t)(b0 + t) * BLK;
         float t1[4], t2[4];
         bool ok[4];
@@ -1013,6 +1025,196 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// pass 2 on KEPT logits.  Same schedule, same V ring, same weight arithmetic and summation order as
+// attend_kernel (the outputs are bit-identical), but the semantic logits of block t+1 are not
+// recomputed (64 of the 321 MFMAs per block and wave): pass 1 left them in HBM in accumulator
+// order, and they arrive like a K tile did - one 1 KB LDS-DMA per wave and block into a 2-slot
+// ring - at 4 B per (query, row) of extra HBM traffic each way, on a kernel that is MFMA-bound.
+// The geographic tile (one MFMA per block) is still recomputed from the X ring.
+// LDS map (bytes): V ring 3 x 32 KB | S ring 2 x 4 KB (1 KB per wave) | X ring 2 x 256 B
+// LDS-DMA groups: E(t) = 8 V pieces, O(t) = 8 V + 1 S + 1 X = 10.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATTEND_STORED_LDS_BYTES = (3 * 8 * VAL_DIM + 2 * 1024 + 2 * 64) * 4;
+
+template <bool GEO>
+__global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* vring = reinterpret_cast<float*>(smem);          // 3 slots x [8][1024]
+    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
+    const uint32_t vring_lds = lds0;
+    const uint32_t sring_lds = lds0 + 3 * 8 * VAL_DIM * 4;
+    const uint32_t xring_lds = sring_lds + 2 * 4096;
+    constexpr uint32_t VS_BYTES = 8 * VAL_DIM * 4;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    int split, qt;
+    decode_block(a, split, qt);
+    const int b0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
+    const int b1 = (int)(((int64_t)(split + 1) * a.n_blocks) / a.n_splits);
+    const int nb = b1 - b0;
+    const int64_t q = (int64_t)qt * QTILE + wave * 16 + (lane & 15);
+    const int64_t qtile_kept = (int64_t)qt + a.qt_offset;
+
+    // per-query constants: w = ca * 2^(k_sem*s - m1) + cb * 2^(k_geo*g - m2)
+    float ca, cb, m1, m2, fxq;
+    {
+        const int64_t qq = q < a.B ? q : a.B - 1;
+        const f32x4 st = *reinterpret_cast<const f32x4*>(a.stats + qq * 4);
+        m1 = st.x; m2 = st.z;
+        ca = a.beta / st.y;
+        cb = GEO ? (1.0f - a.beta) / st.w : 0.f;
+        fxq = a.xq[qq * 4 + g];
+    }
+    // (ordinary loads: put hipcc's wait for them in front of the loop, see pin_qfrag)
+    asm volatile("" : "+v"(ca), "+v"(cb), "+v"(m1), "+v"(m2), "+v"(fxq));
+
+    f32x4 acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* sring_b = smem + 3 * 8 * VAL_DIM * 4;
+    const char* xring_b = sring_b + 2 * 4096;
+    const uint32_t s_rd = (uint32_t)(wave * 1024 + lane * 16);                  // this lane's logits
+    const uint32_t x_rd = (uint32_t)((pi_row(lane & 15) * 4 + g) * 4);          // as KAddr::x
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
+    const int n_left = (int)(a.n_valid - (int64_t)b0 * BLK);
+    const uint32_t vvoff = (uint32_t)(lane << 4);
+
+    // one S tile (this wave's 1 KB) + the X tile: 2 vector-memory operations per wave
+    auto issue_sx = [&](int block, int slot) __attribute__((always_inline)) {
+        dma_b128(a.logits + logit_tile(qtile_kept, a.n_blocks, block, wave), vvoff,
+                 sring_lds + slot * 4096 + wave * 1024);
+        dma_b32(a.xyz4 + (int64_t)block * BLK * 4, (uint32_t)(lane << 2), xring_lds + slot * 256);
+    };
+
+    f32x4 w_cur = {0.f, 0.f, 0.f, 0.f};
+    if (nb > 0) {
+        const int64_t r0 = (int64_t)b0 * BLK;
+        issue_sx(b0, 0);
+        issue_v_half(a.values, r0, vring_lds, wave, lane);
+        issue_v_half(a.values, r0 + 8, vring_lds + VS_BYTES, wave, lane);
+        issue_sx(nb > 1 ? b0 + 1 : b0, 1);
+        RANGE_WAIT_BARRIER(18);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sring_b + s_rd);
+        f32x4 cg = {0.f, 0.f, 0.f, 0.f};
+        if (GEO) {
+            const float xa = *reinterpret_cast<const float*>(xring_b + x_rd);
+            mfma_v_first(cg, xa, fxq);
+            asm volatile("s_nop 15" : "+v"(cg));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wr = ca * __builtin_amdgcn_exp2f(fmaf(sv[r], a.k_sem, -m1));
+            if (GEO) wr = fmaf(cb, __builtin_amdgcn_exp2f(fmaf(cg[r], a.k_geo, -m2)), wr);
+            w_cur[r] = prow[r] < n_left ? wr : 0.f;
+        }
+    }
+    int vs = 0;   // V slot of half 2t
+    PvCarry carry;
+    carry.v0a = carry.v1a = carry.v0b = carry.v1b = f32x4{0.f, 0.f, 0.f, 0.f};
+    carry.w0 = carry.w1 = 0.f;
+    const int b_last = b1 - 1;
+    for (int t = 0; t < nb; ++t) {
+        const int vs1 = vs == 2 ? 0 : vs + 1;
+        const int vs2 = vs1 == 2 ? 0 : vs1 + 1;
+        const int bn1 = min(b0 + t + 1, b_last), bn2 = min(b0 + t + 2, b_last);
+        const float* vsrc1 = a.values + ((int64_t)bn1 * BLK + 2 * wave) * VAL_DIM;     // rows 2w, 2w+1
+        const float* ssrc2 = a.logits + logit_tile(qtile_kept, a.n_blocks, bn2, wave);
+        const float* xsrc2 = a.xyz4 + (int64_t)bn2 * BLK * 4;
+        const uint32_t vdst_e = vring_lds + vs2 * VS_BYTES + wave * 8192;   // half 2t+2
+        const uint32_t vdst_o = vring_lds + vs * VS_BYTES + wave * 8192;    // half 2t+3
+        const uint32_t sdst = sring_lds + (t & 1) * 4096 + wave * 1024;
+        const uint32_t xdst = xring_lds + (t & 1) * 256;
+        // ---- half 2t : leaves O(t-1) = 10 operations in flight
+        RANGE_WAIT_BARRIER(10);
+        {
+            PvOps s0, s1;
+            pv_first_reads(vring + vs * 8 * VAL_DIM, lane, s0, s1);
+            pv_exec_carry(acc, carry);                       // last step of the previous half
+            pv_steps(vring + vs * 8 * VAL_DIM, w_cur[0], w_cur[1], s0, s1, acc, lane, carry,
+                     [&](int h) __attribute__((always_inline)) {
+                         if (h % 14 == 3) {                  // 8 pieces: V half 2t+2
+                             const int ii = h / 14;
+                             if ((ii & 3) == 0) dma_group_begin(vdst_e + (ii >> 2) * 4096);
+                             dma_b128_q(vsrc1 + (ii >> 2) * VAL_DIM, vvoff, ii & 3);
+                         }
+                     });
+        }
+        // ---- half 2t+1 : leaves E(t) = 8 operations in flight
+        RANGE_WAIT_BARRIER(8);
+        PvOps s0, s1;
+        f32x4 cg = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sring_b + ((t + 1) & 1) * 4096 + s_rd);
+        {
+            const float xa = GEO ? *reinterpret_cast<const float*>(xring_b + ((t + 1) & 1) * 256 + x_rd) : 0.f;
+            pv_first_reads(vring + vs1 * 8 * VAL_DIM, lane, s0, s1);
+            pv_exec_carry(acc, carry);                       // last step of half 2t
+            if (GEO) mfma_v_first(cg, xa, fxq);
+        }
+        f32x4 w_next = {0.f, 0.f, 0.f, 0.f};
+        float e1[4], e2[4];
+        const int n_left1 = n_left - (t + 1) * BLK;
+        pv_steps(vring + vs1 * 8 * VAL_DIM, w_cur[2], w_cur[3], s0, s1, acc, lane, carry,
+                [&](int h) __attribute__((always_inline)) {
+                    if ((h & 7) == 3) {
+                        const int ii = h >> 3;               // 10 pieces: V half 2t+3, S/X tile t+2
+                        if (ii < 8) {
+                            if ((ii & 3) == 0) dma_group_begin(vdst_o + (ii >> 2) * 4096);
+                            dma_b128_q(vsrc1 + (8 + (ii >> 2)) * VAL_DIM, vvoff, ii & 3);
+                        } else if (ii == 8) {
+                            dma_b128(ssrc2, vvoff, sdst);
+                        } else if (ii == 9) {
+                            dma_b32(xsrc2, (uint32_t)(lane << 2), xdst);
+                        }
+                    } else if (h >= 21 && h < 101 && ((h - 21) & 3) == 0) {
+                        // weights of block t+1 in slices of <= 4 VALU instructions; the first runs
+                        // >= 20 MFMAs after the geo MFMA, whose result is long readable
+                        const int k = (h - 21) >> 2, r = k / 5, part = k % 5;
+                        if (part == 1) {
+                            e1[r] = fmaf(sv[r], a.k_sem, -m1);
+                            if (GEO) e2[r] = fmaf(cg[r], a.k_geo, -m2);
+                        } else if (part == 2) {
+                            e1[r] = __builtin_amdgcn_exp2f(e1[r]);
+                        } else if (part == 3) {
+                            if (GEO) e2[r] = __builtin_amdgcn_exp2f(e2[r]);
+                        } else if (part == 4) {
+                            float wr = ca * e1[r];
+                            if (GEO) wr = fmaf(cb, e2[r], wr);
+                            w_next[r] = prow[r] < n_left1 ? wr : 0.f;
+                        }
+                    }
+                });
+        w_cur = w_next;
+        vs = vs2;
+    }
+    if (nb > 0) pv_exec_carry(acc, carry);   // last step of the last half
+    // the clamped prefetches of the last iterations are still in flight into this workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    acc_fence(acc);
+    // accumulator tile 4T+c, register r, lane (j,g)  ->  out[query 4g+r of this wave][64T + 4j + c]
+    const int j = lane & 15;
+    const int64_t qw = (int64_t)qt * QTILE + wave * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t qo = qw + 4 * g + r;
+        if (qo < a.B) {
+            float* orow = a.out + ((int64_t)split * a.B + qo) * VAL_DIM + 4 * j;
+#pragma unroll
+            for (int T = 0; T < 16; ++T) {
+                f32x4 o = {acc[4 * T + 0][r], acc[4 * T + 1][r], acc[4 * T + 2][r], acc[4 * T + 3][r]};
+                *reinterpret_cast<f32x4*>(orow + 64 * T) = o;
+            }
+        }
+    }
+}
+
 
 // (n_parts, B, 1024) f32 -> (B, 1024) f32, fixed summation order.
 __global__ void reduce_parts_kernel(const float* parts, int n_parts, int64_t total4, float* out) {

@@ -36,6 +36,11 @@ struct range_ctx {
     DevBuf<float> d_keys, d_values, d_xyz4;
     // workspace
     DevBuf<float> ws_stats_parts, ws_slabs, ws_stats, ws_ehat32, ws_xq, ws_partial, ws_cand_val;
+    // logits kept by the last range_scan_stats(keep_logits = 1): kept_B queries x kept_blocks
+    // bank blocks, 1 KB tiles (attend_kernels.h: logit_tile); kept_B == 0: nothing kept
+    DevBuf<float> ws_logits;
+    int64_t kept_B = 0;
+    int32_t kept_blocks = 0;
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<double> ws_ehat64;
@@ -155,6 +160,8 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.out = nullptr;
     a.cand_val = nullptr;
     a.cand_idx = nullptr;
+    a.logits = nullptr;
+    a.qt_offset = 0;
     if (!pass1) {
         c->last_qtiles = a.n_qtiles;
         c->last_splits = a.n_splits;
@@ -335,6 +342,7 @@ int range_set_bank(range_ctx* c, const float* keys, const float* values, const f
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const int64_t n_pad = (n_rows + BLK - 1) / BLK * BLK;
     c->has_bank = false;
+    c->kept_B = 0;
     HIP_TRY(c->d_keys.ensure((size_t)n_pad * KEY_DIM));
     HIP_TRY(c->d_values.ensure((size_t)n_pad * VAL_DIM));
     HIP_TRY(c->d_xyz4.ensure((size_t)n_pad * 4));
@@ -445,7 +453,7 @@ int range_blend(range_ctx* c, const float* G, const float* H, float beta, int64_
 
 int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
                      float tau_geo, float* stats, int topk, float* topk_val, int64_t* topk_idx,
-                     range_stream_t stream) {
+                     int32_t keep_logits, range_stream_t stream) {
     if (!c || !ehat32 || !xq32 || !stats) return fail(RANGE_ERR_INVALID, "null argument");
     if (topk < 0 || topk > MAX_TOPK) return fail(RANGE_ERR_INVALID, "topk must be in [0,%d]", MAX_TOPK);
     if (topk > 0 && (!topk_val || !topk_idx)) return fail(RANGE_ERR_INVALID, "topk outputs null");
@@ -462,6 +470,20 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
     a.out = c->ws_stats_parts.p;
+    c->kept_B = 0;
+    if (keep_logits && topk == 0) {
+        // 4 B per (query, bank row) of this context's shard; skipped (pass 2 then recomputes)
+        // when that would take more than half of the free device memory
+        const size_t need = (size_t)a.n_qtiles * a.n_blocks * 1024;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (need <= c->ws_logits.n || need * sizeof(float) <= free_b / 2) {
+            HIP_TRY(c->ws_logits.ensure(need));
+            a.logits = c->ws_logits.p;
+            c->kept_B = B;
+            c->kept_blocks = a.n_blocks;
+        }
+    }
     if (topk > 0) {
         HIP_TRY(c->ws_cand_val.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
         HIP_TRY(c->ws_cand_idx.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
@@ -560,10 +582,20 @@ int range_merge_topk(range_ctx* c, const float* val_parts, const int64_t* idx_pa
 
 // pass 2 into the context's split slabs; when `partial` is non-null the slabs are then summed
 // (fixed order) into it, otherwise the caller consumes the slabs (n_splits_out of them) itself.
+// kept_first >= 0: queries [kept_first, kept_first + B) of the last scan whose logits were kept
+// (attend_stored_kernel; ehat32 is not read); kept_first < 0: recompute the logits.
 static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
                        float tau_geo, float beta, const float* stats_global, float* partial,
-                       int* n_splits_out, range_stream_t stream) {
-    if (!c || !ehat32 || !xq32 || !stats_global) return fail(RANGE_ERR_INVALID, "null argument");
+                       int* n_splits_out, int64_t kept_first, range_stream_t stream) {
+    if (!c || (!ehat32 && kept_first < 0) || !xq32 || !stats_global)
+        return fail(RANGE_ERR_INVALID, "null argument");
+    if (kept_first >= 0) {
+        if (c->kept_B <= 0) return fail(RANGE_ERR_STATE, "no kept logits (range_scan_stats with keep_logits)");
+        if (kept_first % QTILE != 0) return fail(RANGE_ERR_INVALID, "first kept query must be a multiple of %d", QTILE);
+        if (kept_first + B > c->kept_B)
+            return fail(RANGE_ERR_INVALID, "queries [%lld, %lld) exceed the %lld kept", (long long)kept_first,
+                        (long long)(kept_first + B), (long long)c->kept_B);
+    }
     if (!(beta >= 0.f && beta <= 1.f)) return fail(RANGE_ERR_INVALID, "beta must be in [0,1]");
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
@@ -577,7 +609,21 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
     const bool geo = tau_geo > 0.f;
     a.beta = geo ? beta : 1.f;
     const dim3 grid((unsigned)(a.n_splits * a.n_qtiles)), block(256);
-    {
+    if (kept_first >= 0) {
+        if (a.n_blocks != c->kept_blocks) return fail(RANGE_ERR_STATE, "bank changed since the logits were kept");
+        a.logits = c->ws_logits.p;
+        a.qt_offset = (int32_t)(kept_first / QTILE);
+        ProfScope ps(c, RANGE_PROF_ATTEND, s);
+        if (geo) {
+            rc = set_dyn_lds(attend_stored_kernel<true>, ATTEND_STORED_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_stored_kernel<true>, grid, block, ATTEND_STORED_LDS_BYTES, s, a);
+        } else {
+            rc = set_dyn_lds(attend_stored_kernel<false>, ATTEND_STORED_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_stored_kernel<false>, grid, block, ATTEND_STORED_LDS_BYTES, s, a);
+        }
+    } else {
         ProfScope ps(c, RANGE_PROF_ATTEND, s);
         if (geo) {
             rc = set_dyn_lds(attend_kernel<true>, ATTEND_LDS_BYTES);
@@ -604,7 +650,18 @@ int range_attend(range_ctx* c, const float* ehat32, const float* xq32, int64_t B
                  float tau_geo, float beta, const float* stats_global, float* partial,
                  range_stream_t stream) {
     if (!partial) return fail(RANGE_ERR_INVALID, "null argument");
-    return attend_impl(c, ehat32, xq32, B, tau_sem, tau_geo, beta, stats_global, partial, nullptr, stream);
+    return attend_impl(c, ehat32, xq32, B, tau_sem, tau_geo, beta, stats_global, partial, nullptr, -1, stream);
+}
+
+int64_t range_kept_queries(const range_ctx* c) { return c ? c->kept_B : 0; }
+
+int range_attend_kept(range_ctx* c, int64_t first_query, const float* xq32, int64_t B, float tau_sem,
+                      float tau_geo, float beta, const float* stats_global, float* partial,
+                      range_stream_t stream) {
+    if (!partial) return fail(RANGE_ERR_INVALID, "null argument");
+    if (first_query < 0) return fail(RANGE_ERR_INVALID, "first_query must be >= 0");
+    return attend_impl(c, nullptr, xq32, B, tau_sem, tau_geo, beta, stats_global, partial, nullptr,
+                       first_query, stream);
 }
 
 // Diagnostic (not part of the product path): same launch as range_attend with the instrumented
@@ -665,13 +722,15 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
     if (rc) return rc;
     rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
-                          nullptr, nullptr, stream);
+                          nullptr, nullptr, /*keep_logits=*/1, stream);
     if (rc) return rc;
     // single GPU: the finalize kernel sums the split slabs itself (same fixed order as
     // reduce_parts_kernel, so the result is bit-identical to attend + finalize)
     int n_splits = 0;
+    // pass 2 consumes the logits pass 1 kept (recomputes them if they did not fit in memory)
     rc = attend_impl(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
-                     model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, &n_splits, stream);
+                     model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, &n_splits,
+                     c->kept_B == B ? 0 : -1, stream);
     if (rc) return rc;
     return range_finalize(c, c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, out, stream);
 }

@@ -73,35 +73,50 @@ class ShardedRange:
         xq_all = self._gather(xq).reshape(W * B, xq.shape[1])
         return e64, e32_all, xq_all
 
+    def _chunk_bounds(self, B: int):
+        """Row ranges [lo,hi) of a rank's queries per chunk.  Boundaries are multiples of 64 (the
+        query-tile size: a chunk then starts on a tile of the kept logits)."""
+        W = self.world
+        n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
+        n_chunks = max(1, min(n_chunks, B // self.min_chunk if B >= self.min_chunk else 1))
+        cuts = sorted({min(B, ((B * c) // n_chunks + 32) // 64 * 64) for c in range(1, n_chunks)})
+        bounds = [0] + [c for c in cuts if 0 < c < B] + [B]
+        return list(zip(bounds[:-1], bounds[1:]))
+
     @torch.no_grad()
     def forward(self, lonlat: torch.Tensor) -> torch.Tensor:
         """lonlat: this rank's (B,2) float64 queries (same B on every rank).
         Returns this rank's (B,1280) float64 embeddings (device tensor)."""
         W, B = self.world, lonlat.shape[0]
         e64, e32_all, xq_all = self._gather_queries(lonlat)
-        stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo)
+        chunks = self._chunk_bounds(B)
+        if len(chunks) > 1:
+            # chunk-major order: rows [lo,hi) of EVERY rank's queries form one chunk, ordered by
+            # owner rank - a contiguous range of the scanned batch whose partial is again W equal
+            # slices, one per destination
+            e32_v = e32_all.reshape(W, B, -1)
+            xq_v = xq_all.reshape(W, B, -1)
+            e32_all = torch.cat([e32_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+            xq_all = torch.cat([xq_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+        # pass 1 on the local shard keeps its logits; pass 2 reads them back instead of
+        # recomputing e . K^T (they are independent of the global statistics)
+        stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
+                                             keep_logits=True)
+        kept = self.engine.kept_queries() == W * B
         stats = self.engine.merge_stats(self._gather(stats_local))
-        n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
-        n_chunks = max(1, min(n_chunks, B // self.min_chunk if B >= self.min_chunk else 1))
-        if n_chunks == 1:
-            partial = self.engine.attend(e32_all, xq_all, self.tau_sem, self.tau_geo, self.beta, stats)
-            mine = torch.empty_like(partial)
-            dist.all_to_all_single(mine, partial, group=self.group)     # (W, B, 1024) slices
-            return self.engine.finalize(mine.reshape(W, B, partial.shape[1]), e64)
-        # chunked: rows [lo,hi) of EVERY rank's queries form one chunk, ordered by owner rank, so
-        # that the chunk's partial is again W equal slices, one per destination
-        e32_v = e32_all.reshape(W, B, -1)
-        xq_v = xq_all.reshape(W, B, -1)
-        st_v = stats.reshape(W, B, -1)
-        bounds = [(B * c) // n_chunks for c in range(n_chunks + 1)]
         pending = []
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            n = hi - lo
-            part = self.engine.attend(e32_v[:, lo:hi].reshape(W * n, -1).contiguous(),
-                                      xq_v[:, lo:hi].reshape(W * n, -1).contiguous(),
-                                      self.tau_sem, self.tau_geo, self.beta,
-                                      st_v[:, lo:hi].reshape(W * n, -1).contiguous())
+        for lo, hi in chunks:
+            first, n = W * lo, W * (hi - lo)
+            if kept:
+                part = self.engine.attend_kept(first, xq_all[first:first + n], self.tau_sem,
+                                               self.tau_geo, self.beta, stats[first:first + n])
+            else:
+                part = self.engine.attend(e32_all[first:first + n], xq_all[first:first + n],
+                                          self.tau_sem, self.tau_geo, self.beta,
+                                          stats[first:first + n])
             recv = torch.empty_like(part)
+            # one direct transfer per peer; asynchronous, so that the exchange of this chunk
+            # overlaps pass 2 of the next
             work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
             pending.append((work, recv, part, lo, hi))
         outs = []
@@ -109,7 +124,7 @@ class ShardedRange:
             work.wait()
             outs.append(self.engine.finalize(recv.reshape(W, hi - lo, recv.shape[1]),
                                              e64[lo:hi].contiguous()))
-        return torch.cat(outs, dim=0)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     __call__ = forward
 

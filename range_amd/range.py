@@ -173,9 +173,13 @@ class LocationEncoder(nn.Module):
         eng = self.engine
         for i in range(0, B, self.chunk_size):
             e64, e32, xq = eng.encode(x[i:i + self.chunk_size])
-            st = eng.scan_stats(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO)
-            H = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 1.0, st)
-            G = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 0.0, st)
+            st = eng.scan_stats(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, keep_logits=True)
+            if eng.kept_queries() == e32.shape[0]:      # both passes 2 from the kept logits
+                H = eng.attend_kept(0, xq, TEMP_RANGE_PLUS, TEMP_GEO, 1.0, st)
+                G = eng.attend_kept(0, xq, TEMP_RANGE_PLUS, TEMP_GEO, 0.0, st)
+            else:
+                H = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 1.0, st)
+                G = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 0.0, st)
             for j, b in enumerate(betas):
                 out[j, i:i + e64.shape[0]] = eng.finalize(eng.blend(G, H, b), e64)
         return out if return_device else out.cpu().numpy()

@@ -25,6 +25,8 @@ class OracleShardEngine:
 
     def __init__(self, weights, L, bank: O.Bank, row_offset: int):
         self.w, self.L, self.bank, self.row_offset = weights, L, bank, row_offset
+        self._kept = None
+        self.keep_ok = True       # False: behave like an engine whose logits did not fit
 
     def encode(self, lonlat):
         q = lonlat.numpy()
@@ -38,7 +40,8 @@ class OracleShardEngine:
         g = xq.numpy()[:, :3].astype(np.float64) @ self.bank.xyz.astype(np.float64).T
         return s, g
 
-    def scan_stats(self, e32, xq, tau_sem, tau_geo, topk=0):
+    def scan_stats(self, e32, xq, tau_sem, tau_geo, topk=0, keep_logits=False):
+        self._kept = e32.clone() if keep_logits and self.keep_ok and not topk else None
         s, g = self._logits(e32, xq)
         st = np.zeros((s.shape[0], 4), np.float64)
         t = s * tau_sem * LOG2E
@@ -70,6 +73,13 @@ class OracleShardEngine:
         if tau_geo > 0:
             w = w + (1 - beta) * np.exp2(g * tau_geo * LOG2E - st[:, 2:3]) / st[:, 3:4]
         return torch.from_numpy((w @ self.bank.values.astype(np.float64)).astype(np.float32))
+
+    def kept_queries(self):
+        return 0 if self._kept is None else self._kept.shape[0]
+
+    def attend_kept(self, first, xq, tau_sem, tau_geo, beta, stats):
+        assert first % 64 == 0 and first + xq.shape[0] <= self._kept.shape[0]
+        return self.attend(self._kept[first:first + xq.shape[0]], xq, tau_sem, tau_geo, beta, stats)
 
     def finalize(self, partials, e64):
         acc = partials[0].clone()
@@ -104,9 +114,13 @@ def _worker(rank, world, port, N, B, L, H, ret):
         shard = O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1])
         w = synth.make_encoder_weights(L, H, 256, 2, 5)
         q = synth.make_queries(B, seed=100 + rank)
-        for name, beta, chunks in (("RANGE+", 0.5, 1), ("RANGE+", 0.0, 3), ("RANGE", None, 2)):
-            model = ShardedRange(OracleShardEngine(w, L, shard, r0), name, beta, n_chunks=chunks)
-            model.min_chunk = 2          # exercise the chunked, overlapped exchange on tiny batches
+        for name, beta, chunks, keep in (("RANGE+", 0.5, 1, True), ("RANGE+", 0.0, 3, True),
+                                         ("RANGE", None, 2, True), ("RANGE+", 0.25, 3, False)):
+            eng = OracleShardEngine(w, L, shard, r0)
+            eng.keep_ok = keep           # False: the engine could not keep its logits
+            model = ShardedRange(eng, name, beta, n_chunks=chunks)
+            model.min_chunk = 2          # exercise the chunked, overlapped exchange on small batches
+            assert len(model._chunk_bounds(B)) == min(chunks, max(1, B // 64))
             out = model(torch.from_numpy(q)).numpy()
             ref = O.forward(q, w, L, full, name, beta)      # unsharded oracle, own queries
             err = float(np.abs(out - ref).max())
@@ -127,7 +141,7 @@ def _worker(rank, world, port, N, B, L, H, ret):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_forward_gloo(world):
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), 601, 9, 10, 64, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), 601, 200, 10, 64, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
 
 

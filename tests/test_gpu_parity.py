@@ -473,3 +473,43 @@ def test_coordinate_encoders_vs_reference_golden():
         np.testing.assert_allclose(got, O.coord_features(big, name), rtol=0, atol=4e-16)
     with pytest.raises(ValueError):
         load_model("Wrap")                                     # load_model.py:31-32 applies to all
+
+
+@pytest.mark.parametrize("N,B", [(500, 33), (1537, 64), (16, 1), (4099, 200), (20000, 300)])
+def test_attend_kept_is_bit_identical(N, B):
+    """Pass 2 from the logits pass 1 kept == pass 2 that recomputes them, bit for bit: whole
+    batch, sub-ranges starting on a query tile, both heads, another beta / temperature."""
+    locs, vals, keys = synth.make_bank(N, 5)
+    bank = O.prep_bank(locs, vals, keys)
+    w, enc = _params(10, 64, 2, 5)
+    eng = _engine(enc, bank)
+    q = synth.make_queries(B, seed=N + B)
+    _, e32, xq = eng.encode(_dev(q))
+    for tau_geo in (40.0, 0.0):
+        st = eng.scan_stats(e32, xq, 12.0, tau_geo, keep_logits=True)
+        assert eng.kept_queries() == B
+        for beta in ((0.5, 0.0, 1.0) if tau_geo > 0 else (1.0,)):
+            ref = eng.attend(e32, xq, 12.0, tau_geo, beta, st)
+            got = eng.attend_kept(0, xq, 12.0, tau_geo, beta, st)
+            assert torch.equal(ref, got)
+        for first in range(64, B, 64):
+            for n in {1, min(70, B - first), B - first}:
+                ref = eng.attend(e32[first:first + n], xq[first:first + n], 12.0, tau_geo, 0.5,
+                                 st[first:first + n])
+                got = eng.attend_kept(first, xq[first:first + n], 12.0, tau_geo, 0.5,
+                                      st[first:first + n])
+                assert torch.equal(ref, got)
+    # the kept values are un-scaled: another temperature reuses them
+    st15 = eng.scan_stats(e32, xq, 15.0, 0.0)                  # (does not keep: kept set dropped)
+    assert eng.kept_queries() == 0
+    with pytest.raises(_native.RangeNativeError):
+        eng.attend_kept(0, xq, 15.0, 0.0, 1.0, st15)
+    eng.scan_stats(e32, xq, 12.0, 40.0, keep_logits=True)
+    assert torch.equal(eng.attend_kept(0, xq, 15.0, 0.0, 1.0, st15),
+                       eng.attend(e32, xq, 15.0, 0.0, 1.0, st15))
+    with pytest.raises(_native.RangeNativeError):
+        eng.attend_kept(32, xq[32:], 12.0, 40.0, 0.5, st15[32:])        # not on a query tile
+    with pytest.raises(_native.RangeNativeError):
+        eng.attend_kept(0, torch.cat([xq, xq]), 12.0, 40.0, 0.5, torch.cat([st15, st15]))
+    _, tv, ti = eng.scan_stats(e32, xq, 12.0, 0.0, topk=4, keep_logits=True)   # top-k variant: no keep
+    assert eng.kept_queries() == 0
