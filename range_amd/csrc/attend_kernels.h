@@ -4,12 +4,14 @@
 //     H = softmax_N(tau_sem * e . K^T) @ V,   G = softmax_N(tau_geo * x . X^T) @ V,
 //     M = (1-beta) * G + beta * H
 // with N = ALL bank rows (dense soft attention, no top-k truncation).  The reference materialises
-// the (B,N) matrices; here nothing of size B*N ever reaches HBM:
+// two (B,N) probability matrices and multiplies each with V; here:
 //
-//   pass 1  scan_stats_kernel   per query running (max, sum-exp) of both logit rows
-//   pass 2  attend_kernel       recomputes the logits, forms ONE combined weight
-//                               w = beta*p_sem + (1-beta)*p_geo and accumulates w @ V once
-//                               (3084 FLOP per (query,row) pair instead of 4614).
+//   pass 1  scan_stats_kernel     per query running (max, sum-exp) of both logit rows; the raw
+//                                 semantic logits are kept in HBM (4 B per (query,row) pair)
+//   pass 2  attend_stored_kernel  reads them back, forms ONE combined weight
+//                                 w = beta*p_sem + (1-beta)*p_geo and accumulates w @ V once
+//                                 (2572 FLOP per pair over both passes instead of 4614)
+//           attend_kernel         the same, recomputing the logits (when they were not kept)
 //
 // Both passes are FP32-MFMA bound (v_mfma_f32_16x16x4_f32: exact f32 products, bitwise an fmaf
 // chain), not HBM bound - see DESIGN.md.  Work decomposition (identical in both passes):
@@ -288,7 +290,14 @@ __device__ __forceinline__ void issue_v_half(const float* values, int64_t row0, 
 
 // wait for all but the n youngest vector-memory operations of this wave, then workgroup barrier.
 // One asm statement with a memory clobber: no LDS access may be moved across it by the compiler.
+// RANGE_EXP_NOBAR / RANGE_EXP_NODMA / RANGE_EXP_NOLDS: tuning experiments only (./build.sh -D...):
+// they drop the barriers / the in-loop LDS-DMA issue / the V operand reads of pass 2 to price
+// each of them; the results of such a build are garbage.
+#ifdef RANGE_EXP_NOBAR
+#define RANGE_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory")
+#else
 #define RANGE_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // Diagnostic build only (attend_kernel<GEO, true>, never on the product path): s_memtime stamps
 // around the two parts of a wait so that their cycles can be summed per wave.
@@ -788,8 +797,12 @@ __device__ __forceinline__ void pv_steps(const float* vslot, float w0, float w1,
     for (int T = 0; T < 14; ++T) {
         // lane (j,g) reads V[row 2g+rr][64T + 4j .. +3]: one ds_read_b128 feeds 4 accumulator
         // tiles; the reads of step T+2 sit in front of step T's 8 MFMAs (512 cycles of cover)
+#ifdef RANGE_EXP_NOLDS
+        const f32x4 m0 = v1, m1 = v0;
+#else
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(base + 64 * (T + 2));
         const f32x4 m1 = *reinterpret_cast<const f32x4*>(base + VAL_DIM + 64 * (T + 2));
+#endif
         RANGE_PV_MFMA(4 * T + 0, w0, v0.x, 8 * T + 0);
         RANGE_PV_MFMA(4 * T + 1, w0, v0.y, 8 * T + 1);
         RANGE_PV_MFMA(4 * T + 2, w0, v0.z, 8 * T + 2);
@@ -1139,11 +1152,13 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
             pv_exec_carry(acc, carry);                       // last step of the previous half
             pv_steps(vring + vs * 8 * VAL_DIM, w_cur[0], w_cur[1], s0, s1, acc, lane, carry,
                      [&](int h) __attribute__((always_inline)) {
+#ifndef RANGE_EXP_NODMA
                          if (h % 14 == 3) {                  // 8 pieces: V half 2t+2
                              const int ii = h / 14;
                              if ((ii & 3) == 0) dma_group_begin(vdst_e + (ii >> 2) * 4096);
                              dma_b128_q(vsrc1 + (ii >> 2) * VAL_DIM, vvoff, ii & 3);
                          }
+#endif
                      });
         }
         // ---- half 2t+1 : leaves E(t) = 8 operations in flight
@@ -1162,8 +1177,13 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
         const int n_left1 = n_left - (t + 1) * BLK;
         pv_steps(vring + vs1 * 8 * VAL_DIM, w_cur[2], w_cur[3], s0, s1, acc, lane, carry,
                 [&](int h) __attribute__((always_inline)) {
+#ifdef RANGE_EXP_NODMA
+                    if (false) {
+                        const int ii = 0;
+#else
                     if ((h & 7) == 3) {
                         const int ii = h >> 3;               // 10 pieces: V half 2t+3, S/X tile t+2
+#endif
                         if (ii < 8) {
                             if ((ii & 3) == 0) dma_group_begin(vdst_o + (ii >> 2) * 4096);
                             dma_b128_q(vsrc1 + (8 + (ii >> 2)) * VAL_DIM, vvoff, ii & 3);
@@ -1172,22 +1192,19 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
                         } else if (ii == 9) {
                             dma_b32(xsrc2, (uint32_t)(lane << 2), xdst);
                         }
-                    } else if (h >= 21 && h < 101 && ((h - 21) & 3) == 0) {
-                        // weights of block t+1 in slices of <= 4 VALU instructions; the first runs
-                        // >= 20 MFMAs after the geo MFMA, whose result is long readable
-                        const int k = (h - 21) >> 2, r = k / 5, part = k % 5;
-                        if (part == 1) {
-                            e1[r] = fmaf(sv[r], a.k_sem, -m1);
-                            if (GEO) e2[r] = fmaf(cg[r], a.k_geo, -m2);
-                        } else if (part == 2) {
-                            e1[r] = __builtin_amdgcn_exp2f(e1[r]);
-                        } else if (part == 3) {
-                            if (GEO) e2[r] = __builtin_amdgcn_exp2f(e2[r]);
-                        } else if (part == 4) {
-                            float wr = ca * e1[r];
-                            if (GEO) wr = fmaf(cb, e2[r], wr);
-                            w_next[r] = prow[r] < n_left1 ? wr : 0.f;
-                        }
+                    } else if (h >= 22 && h < 78 && (h & 1) == 0) {
+                        // weights of block t+1, ONE VALU instruction per MFMA gap (an exp2 is a
+                        // quarter-rate instruction: two of them in one gap delay the next MFMA);
+                        // even h only, the LDS-DMA pieces sit on odd h.  The first runs > 20
+                        // MFMAs after the geo MFMA, whose result is long readable.
+                        const int k = (h - 22) >> 1, r = k / 7, op = k % 7;
+                        if (op == 0) e1[r] = fmaf(sv[r], a.k_sem, -m1);
+                        else if (op == 1) { if (GEO) e2[r] = fmaf(cg[r], a.k_geo, -m2); }
+                        else if (op == 2) e1[r] = __builtin_amdgcn_exp2f(e1[r]);
+                        else if (op == 3) { if (GEO) e2[r] = __builtin_amdgcn_exp2f(e2[r]); }
+                        else if (op == 4) e1[r] = ca * e1[r];
+                        else if (op == 5) { if (GEO) e1[r] = fmaf(cb, e2[r], e1[r]); }
+                        else w_next[r] = prow[r] < n_left1 ? e1[r] : 0.f;
                     }
                 });
         w_cur = w_next;

@@ -21,11 +21,21 @@ x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
 e64, e32, xq = eng.encode(x)
 st = eng.scan_stats(e32, xq, 12.0, 40.0)
 st_ok = torch.zeros_like(st); st_ok[:, 0] = 17.0; st_ok[:, 1] = 100.0; st_ok[:, 2] = 57.0; st_ok[:, 3] = 100.0
-for _ in range(3):
-    eng.encode(x); eng.scan_stats(e32, xq, 12.0, 40.0); eng.attend(e32, xq, 12.0, 40.0, 0.5, st_ok)
-eng.profile_enable(True)
-for _ in range(steps):
-    eng.encode(x); eng.scan_stats(e32, xq, 12.0, 40.0); eng.attend(e32, xq, 12.0, 40.0, 0.5, st_ok)
-torch.cuda.synchronize()
 names = ["encoder", "scan_stats", "attend"]
-print({n: round(eng.profile_read(i)[0] / steps, 4) for i, n in enumerate(names)})
+for kept in (False, True):        # pass 2 recomputing the logits / on the logits pass 1 kept
+    def one():
+        eng.encode(x)
+        eng.scan_stats(e32, xq, 12.0, 40.0, keep_logits=kept)
+        if kept:
+            eng.attend_kept(0, xq, 12.0, 40.0, 0.5, st_ok)
+        else:
+            eng.attend(e32, xq, 12.0, 40.0, 0.5, st_ok)
+    for _ in range(3):
+        one()
+    eng.profile_enable(True)
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    print("kept logits" if kept else "recompute  ",
+          {n: round(eng.profile_read(i)[0] / steps, 4) for i, n in enumerate(names)})
+    eng.profile_enable(False)
