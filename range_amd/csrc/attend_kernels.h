@@ -207,7 +207,11 @@ __device__ __forceinline__ void qk_mfma(const char* kt, const KFirst& first, con
     for (int s = 0; s < 16; ++s) {
         const f32x4 ka = kn;
         kn = kn2;
+#ifdef RANGE_EXP_P1_NOLDS
+        if (s < 14) kn2 = ka;
+#else
         if (s < 14) kn2 = *reinterpret_cast<const f32x4*>(kt + ka_.b[(s + 2) & 3] + 256 * ((s + 2) >> 2));
+#endif
         if (s == 0) {
             mfma_v_first(c.a0, ka.x, f.q[s].x);
             mfma_v_first(c.a1, ka.y, f.q[s].y);
@@ -389,11 +393,13 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     int slot = 0;
     for (int t = 0; t < nb; ++t) {
         RANGE_WAIT_BARRIER(0);
+#ifndef RANGE_EXP_P1_NODMA
         if (t + 1 < nb) {
             const int s2 = slot ^ 1;
             issue_k_tile(a.keys, a.xyz4, (int64_t)(b0 + t + 1) * BLK, kring_lds + s2 * KT_BYTES,
                          xring_lds + s2 * 256, wave, lane, swz);
         }
+#endif
         QKAcc c;
         qk_mfma<GEO>(smem + slot * KT_BYTES,
                      qk_first_reads<GEO>(smem + slot * KT_BYTES, smem + 2 * KT_BYTES + slot * 256, kaddr),
@@ -414,6 +420,7 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             if (GEO) t2[r] = ok[r] ? sg[r] * a.k_geo : NEG_BIG;
             if (TOPK) { if (ok[r]) tk.push(ss[r], (int32_t)row); }
         }
+#ifndef RANGE_EXP_P1_NOVALU
         {
             const float mx = fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3]));
             const float mn = fmaxf(m1, mx);
@@ -430,6 +437,9 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t2[r] - mn) : 0.f;
             l2 = acc; m2 = mn;
         }
+#else
+        l1 += t1[0] + t1[3]; if (GEO) l2 += t2[1];
+#endif
         slot ^= 1;
     }
     // lanes j, j+16, j+32, j+48 hold disjoint row subsets of the same query
