@@ -121,7 +121,8 @@ int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev,
  *   keep_logits : non-zero (with topk == 0): also keep the raw semantic dot products of this call
  *          in the context (4 bytes per (query, bank row) of workspace) for range_attend_kept.  They
  *          stay valid until the next range_scan_stats / range_set_bank on this ctx.  Silently not
- *          kept when they would take more than half of the free device memory. */
+ *          kept when they would take more than half of the free device memory, or when the
+ *          context was created with RANGE_KEEP_LOGITS=0 in the environment (A/B timing, tests). */
 int range_scan_stats(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
                      float tau_sem, float tau_geo, float* stats_dev, int topk,
                      float* topk_val_dev, int64_t* topk_idx_dev, int32_t keep_logits,

@@ -41,6 +41,7 @@ struct range_ctx {
     DevBuf<float> ws_logits;
     int64_t kept_B = 0;
     int32_t kept_blocks = 0;
+    bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<double> ws_ehat64;
@@ -192,6 +193,8 @@ int range_create(int device, range_ctx** out) {
     if (!c) return fail(RANGE_ERR_NOMEM, "out of host memory");
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* keep = std::getenv("RANGE_KEEP_LOGITS");
+    c->allow_keep = !(keep && keep[0] == '0');
     *out = c;
     return RANGE_OK;
 }
@@ -471,7 +474,7 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
     a.out = c->ws_stats_parts.p;
     c->kept_B = 0;
-    if (keep_logits && topk == 0) {
+    if (keep_logits && topk == 0 && c->allow_keep) {
         // 4 B per (query, bank row) of this context's shard; skipped (pass 2 then recomputes)
         // when that would take more than half of the free device memory
         const size_t need = (size_t)a.n_qtiles * a.n_blocks * 1024;

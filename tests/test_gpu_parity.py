@@ -513,3 +513,19 @@ def test_attend_kept_is_bit_identical(N, B):
         eng.attend_kept(0, torch.cat([xq, xq]), 12.0, 40.0, 0.5, torch.cat([st15, st15]))
     _, tv, ti = eng.scan_stats(e32, xq, 12.0, 0.0, topk=4, keep_logits=True)   # top-k variant: no keep
     assert eng.kept_queries() == 0
+
+
+def test_forward_without_kept_logits_is_identical(tmp_path, monkeypatch):
+    """RANGE_KEEP_LOGITS=0 makes a context recompute the logits in pass 2 (the path taken when the
+    kept logits would not fit in memory): same embeddings, bit for bit."""
+    from range_amd import load_model
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 3001, seed=8)
+    q = torch.from_numpy(synth.make_queries(333, seed=4)).to("cuda:0")
+    outs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("RANGE_KEEP_LOGITS", env)
+        m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=0.3)
+        outs.append(m(q))
+        assert (m.engine.kept_queries() == 333) == (env == "1")
+    assert np.array_equal(outs[0], outs[1])
