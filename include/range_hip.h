@@ -117,8 +117,12 @@ int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev,
  *               range_merge_stats.
  *   topk : 0, or k in [1,16]: also emit the k largest semantic similarities of each query
  *          (the "brute-force top-k" side channel), descending, ties -> lower row index:
- *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local)
- *   keep_logits : non-zero (with topk == 0): also keep the raw semantic dot products of this call
+ *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local).
+ *          The similarities are written to HBM by pass 1 and the top-k is selected from them
+ *          by a streaming kernel with a per-query threshold (list maintenance inside pass 1
+ *          costs more than its MFMAs); a context that cannot keep logits (memory,
+ *          RANGE_KEEP_LOGITS=0) keeps per-lane lists inside pass 1 instead.  Same result.
+ *   keep_logits : non-zero: keep the raw semantic dot products of this call
  *          in the context (4 bytes per (query, bank row) of workspace) for range_attend_kept.  They
  *          stay valid until the next range_scan_stats / range_set_bank on this ctx.  Silently not
  *          kept when they would take more than half of the free device memory, or when the

@@ -76,6 +76,10 @@ struct ScanArgs {
     // non-null; attend_stored_kernel reads them instead of recomputing K . Q^T.
     float* logits;
     int32_t qt_offset;          // pass 2 on a sub-range of the scanned queries: first query / 64
+    // pass 1, optional: (nsplit,B,4) largest semantic similarity each lane group met - disjoint
+    // row subsets, so the 16th largest of a query's entries bounds its 16th best similarity from
+    // below (the threshold of topk_from_logits_kernel)
+    float* rowmax;
 };
 
 // float offset of the kept-logit tile of (query tile, bank block, wave)
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     kaddr.init(lane);
 
     float m1 = NEG_BIG, l1 = 0.f, m2 = NEG_BIG, l2 = 0.f;
+    float smax = -INFINITY;      // largest similarity of this lane's rows (a.rowmax)
     TopK<TOPK ? MAX_TOPK : 1> tk;
     if (TOPK) tk.init();
 
@@ -420,6 +425,9 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             if (GEO) t2[r] = ok[r] ? sg[r] * a.k_geo : NEG_BIG;
             if (TOPK) { if (ok[r]) tk.push(ss[r], (int32_t)row); }
         }
+        if (a.rowmax)
+            smax = fmaxf(smax, fmaxf(fmaxf(ok[0] ? ss[0] : -INFINITY, ok[1] ? ss[1] : -INFINITY),
+                                     fmaxf(ok[2] ? ss[2] : -INFINITY, ok[3] ? ss[3] : -INFINITY)));
 #ifndef RANGE_EXP_P1_NOVALU
         {
             const float mx = fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3]));
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     }
     if (!GEO) { m2 = NEG_BIG; l2 = 0.f; }   // "no rows": stays so under any merge
     if (q < a.B) {
+        if (a.rowmax) a.rowmax[((int64_t)split * a.B + q) * 4 + g] = smax;   // before the lane merge
         if (g == 0) {
             f32x4 o = {m1, l1, m2, l2};
             *reinterpret_cast<f32x4*>(a.out + ((int64_t)split * a.B + q) * 4) = o;
@@ -542,24 +551,36 @@ struct TopkStreamArgs {
     int32_t n_blocks;
 };
 
-constexpr int TOPKS_LDS_BYTES = 4 * 2 * BLK * KEY_DIM * 4;   // 4 waves x 2 tiles x 16 KB
+// WAVES waves per workgroup, each with a private ring of DEPTH key tiles (DEPTH-1 of them in
+// flight while one is consumed); WAVES * DEPTH * 16 KB of LDS.  Measured (tools/
+// topk_stream_sweep.sh): the bare LDS-DMA stream tops out at 5.6 TB/s for any
+// geometry; with the MFMAs and the list maintenance (the costliest part: 1.6 us per tile and
+// wave, every wave sees too few rows for its lists to saturate) 4 waves x 2 slots is fastest.
+// RANGE_EXP_TS_NOPUSH / RANGE_EXP_TS_NOMFMA: timing experiments only (results invalid).
+template <int WAVES, int DEPTH>
+constexpr int topks_lds_bytes() { return WAVES * DEPTH * BLK * KEY_DIM * 4; }
 
-__global__ __launch_bounds__(256) void topk_stream_kernel(TopkStreamArgs a) {
+template <int WAVES, int DEPTH>
+__global__ __launch_bounds__(WAVES * 64) void topk_stream_kernel(TopkStreamArgs a) {
+    static_assert(WAVES <= 4 && (DEPTH - 1) * 16 <= 63, "list merge uses 4 lane groups; vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * 2 * KT_BYTES;
-    const char* my = smem + wave * 2 * KT_BYTES;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * DEPTH * KT_BYTES;
+    const char* my = smem + wave * DEPTH * KT_BYTES;
 
     const int group = blockIdx.y;
     const int64_t q = (int64_t)group * 16 + (lane & 15);
-    const int n_waves = gridDim.x * 4;
-    const int w_id = blockIdx.x * 4 + wave;
-    // one tile = 16 rows = 16 DMA instructions (4 groups of 4 rows, swizzled source)
+    const int n_waves = gridDim.x * WAVES;
+    const int w_id = blockIdx.x * WAVES + wave;
+    // one tile = 16 rows = 16 DMA instructions (4 groups of 4 rows, swizzled source); past the
+    // end of the bank the last tile is fetched again (never consumed), so that every wait below
+    // is a constant
+    const int last = a.n_blocks - 1;
     auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
-        const float* src = a.keys + (int64_t)tile * BLK * KEY_DIM;
+        const float* src = a.keys + (int64_t)(tile < last ? tile : last) * BLK * KEY_DIM;
 #pragma unroll
         for (int gr = 0; gr < 4; ++gr) {
             dma_group_begin(lds0 + slot * KT_BYTES + gr * 4096);
@@ -568,8 +589,10 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkStreamArgs a) {
                 dma_b128_q(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i)) << 4), i);
         }
     };
-    int tile = w_id, slot = 0;
-    if (tile < a.n_blocks) issue_tile(tile, 0);      // first keys on their way before anything else
+    // first keys on their way before anything else: tiles t0, t0+n_waves, ... into slots 0..DEPTH-2
+    int tile = w_id;
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue_tile(w_id + d * n_waves, d);
     QFrag f;
     load_qfrag(f, a.ehat, a.ehat, a.B, q, g);        // (xq unused: semantic head only)
     pin_qfrag(f);
@@ -580,30 +603,39 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkStreamArgs a) {
     for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
     KeyList L;
     L.init();
+    int slot = 0;
     for (; tile < a.n_blocks; tile += n_waves) {
-        const int next = tile + n_waves;
-        if (next < a.n_blocks) {
-            issue_tile(next, slot ^ 1);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // refill the slot consumed in the previous iteration, then wait for this iteration's
+        // tile: the DEPTH-1 younger tiles (16 operations each) may stay in flight
+        issue_tile(tile + (DEPTH - 1) * n_waves, slot == 0 ? DEPTH - 1 : slot - 1);
+        if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         QKAcc c;
         const char* kt = my + slot * KT_BYTES;
+#ifdef RANGE_EXP_TS_NOMFMA
+        c.a0 = c.a1 = c.a2 = c.a3 = *reinterpret_cast<const f32x4*>(kt + lane * 16);
+#else
         qk_mfma<false>(kt, qk_first_reads<false>(kt, kt, kaddr), kaddr, f, c,
                        [](int) __attribute__((always_inline)) {});
         c.fence();
+#endif
         const int64_t row0 = (int64_t)tile * BLK;
+#ifdef RANGE_EXP_TS_NOPUSH
+        L.k[0] += (unsigned long long)__float_as_uint(c.sem(0) + c.sem(1) + c.sem(2) + c.sem(3)) + row0;
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + prow[r];
             if (row < a.n_valid) L.push(topk_key(c.sem(r), (uint32_t)row));
         }
+#endif
         // all LDS reads of this tile are complete (their results fed the MFMAs above) before
         // the next iteration's DMA may overwrite the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        slot ^= 1;
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end
     // per-query merge: lane groups -> waves -> one list per workgroup
     merge_lane_groups(L);
     __syncthreads();                                   // ring no longer needed: reuse LDS
@@ -616,7 +648,8 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkStreamArgs a) {
     if (wave == 0) {
         KeyList M;
 #pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[(g * 16 + (lane & 15)) * MAX_TOPK + i];
+        for (int i = 0; i < MAX_TOPK; ++i)
+            M.k[i] = g < WAVES ? sh[(g * 16 + (lane & 15)) * MAX_TOPK + i] : 0ull;
         merge_lane_groups(M);
         if (g == 0) {
             unsigned long long* o = a.cand + (((int64_t)group * gridDim.x + blockIdx.x) * 16 + (lane & 15)) * MAX_TOPK;
@@ -689,6 +722,127 @@ __global__ __launch_bounds__(512) void merge_lists_kernel(const unsigned long lo
     }
 }
 
+// theta[q] = the 16th largest of the n_parts*4 per-lane-group maxima pass 1 recorded for query q
+// (-inf when there are fewer than 16): a lower bound of the query's 16th best similarity, and a
+// tight one - with 52 groups about 20 of 100 000 values reach it.  One wave per query.
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ rowmax,
+                                                             int n_parts, int64_t B,
+                                                             float* __restrict__ theta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= B) return;
+    KeyList L;
+    L.init();
+    const int total = n_parts * 4;
+    for (int e = lane; e < total; e += 64) {
+        const float v = rowmax[((int64_t)(e >> 2) * B + q) * 4 + (e & 3)];
+        if (v > -INFINITY) L.push(topk_key(v, (uint32_t)e));
+    }
+    merge_wave(L);
+    if (lane == 0) theta[q] = L.k[MAX_TOPK - 1] ? topk_key_val(L.k[MAX_TOPK - 1]) : -INFINITY;
+}
+
+// Top-k from the KEPT logits (large batches): the semantic similarities of pass 1 are already in
+// HBM, one 1 KB tile per (query tile, 16-row block, wave slot); this kernel streams them back
+// (HBM-bound: 4 B per (query,row) pair) and keeps a running top-16 per lane.  A lane sees thousands
+// of values here, so its list saturates and nearly every value fails the first comparison -
+// unlike inside pass 1, where the list maintenance of the TOPK variant costs more than the MFMAs.
+// One wave per (wave slot of 16 queries, chunk of blocks); lane (j,g) reads the float4 of rows
+// pi_row(4g+r); the 4 lane groups of a query are merged and one sorted list of 16 (value, local
+// row) goes to cval/cidx[(chunk*B + query)*16 ...], merged across chunks by merge_topk_wave_kernel.
+__global__ __launch_bounds__(256) void topk_from_logits_kernel(const float* __restrict__ logits,
+                                                               int32_t n_blocks, int64_t B,
+                                                               int64_t n_valid, int32_t n_chunks,
+                                                               const float* __restrict__ theta,
+                                                               float* __restrict__ cval,
+                                                               int32_t* __restrict__ cidx) {
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (query tile, wave)
+    const int64_t n_slots = (B + 15) / 16;
+    if (slot >= n_slots) return;
+    const int chunk = blockIdx.y;
+    const int b0 = (int)(((int64_t)chunk * n_blocks) / n_chunks);
+    const int b1 = (int)(((int64_t)(chunk + 1) * n_blocks) / n_chunks);
+    // tile (qtile, b, wave) sits at ((qtile * n_blocks + b) * 4 + wave) * 256 floats
+    const float* base = logits + ((slot >> 2) * (int64_t)n_blocks * 4 + (slot & 3)) * 256 + 4 * lane;
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
+    KeyList L;
+    L.init();
+    // lower bound of this lane's query's 16th best similarity (topk_threshold_kernel): only the
+    // few values that reach it are candidates, so the (wave-divergent) insertion is rare
+    const int64_t qq = slot * 16 + (lane & 15);
+    const float th = theta[qq < B ? qq : B - 1];
+    constexpr int UNROLL = 8;
+    for (int b = b0; b < b1; b += UNROLL) {
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int bb = b + u < b1 ? b + u : b1 - 1;
+            v[u] = *reinterpret_cast<const f32x4*>(base + (int64_t)bb * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (b + u < b1) {
+                const int64_t row0 = (int64_t)(b + u) * BLK;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + prow[r];
+                    if (v[u][r] >= th && row < n_valid) L.push(topk_key(v[u][r], (uint32_t)row));
+                }
+            }
+        }
+    }
+    merge_lane_groups(L);
+    const int64_t q = slot * 16 + (lane & 15);
+    if (g == 0 && q < B) {
+        float* ov = cval + ((int64_t)chunk * B + q) * MAX_TOPK;
+        int32_t* oi = cidx + ((int64_t)chunk * B + q) * MAX_TOPK;
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) {
+            const unsigned long long mm = L.k[i];
+            ov[i] = mm ? topk_key_val(mm) : -INFINITY;
+            oi[i] = mm ? (int32_t)topk_key_row(mm) : 0x7fffffff;
+        }
+    }
+}
+
+// Top-k of the pass-1 candidates of one query (scan_stats_kernel<.., true>): one WAVE per query.
+// cval / cidx: (n_parts, B, per_part) sorted-by-lane-group candidate values and LOCAL rows
+// (0x7fffffff = empty).  Lane l folds candidates l, l+64, ... into a register list, the wave then
+// extracts the k best (ties -> lower row) by shuffles.
+__global__ __launch_bounds__(256) void merge_topk_wave_kernel(const float* __restrict__ cval,
+                                                              const int32_t* __restrict__ cidx,
+                                                              int n_parts, int64_t B, int per_part,
+                                                              int k, int64_t row_offset,
+                                                              float* __restrict__ oval,
+                                                              int64_t* __restrict__ oidx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= B) return;
+    KeyList L;
+    L.init();
+    const int total = n_parts * per_part;
+    for (int e = lane; e < total; e += 64) {
+        const int p = e / per_part, c = e - p * per_part;
+        const int64_t at = ((int64_t)p * B + q) * per_part + c;
+        const int32_t row = cidx[at];
+        if (row != 0x7fffffff) L.push(topk_key(cval[at], (uint32_t)row));
+    }
+    merge_wave(L);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) {
+            if (i < k) {
+                const unsigned long long mm = L.k[i];
+                oval[q * k + i] = mm ? topk_key_val(mm) : -INFINITY;
+                oidx[q * k + i] = mm ? (int64_t)topk_key_row(mm) + row_offset : (int64_t)-1;
+            }
+        }
+    }
+}
+
 // (n_parts,B,4) -> (B,4): exact log-sum-exp merge, fixed order.
 __global__ void merge_stats_kernel(const float* parts, int n_parts, int64_t B, float* out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,6 +855,32 @@ __global__ void merge_stats_kernel(const float* parts, int n_parts, int64_t B, f
     }
     f32x4 o = {m1, l1, m2, l2};
     *reinterpret_cast<f32x4*>(out + q * 4) = o;
+}
+
+// The same merge with one WAVE per query, for the many-split launches of small batches (a
+// thread walking 1000+ parts one dependent load at a time takes 0.4 ms): lane l folds parts
+// l, l+64, ..., then a fixed butterfly of shuffles.
+__global__ __launch_bounds__(256) void merge_stats_wave_kernel(const float* __restrict__ parts,
+                                                               int n_parts, int64_t B,
+                                                               float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= B) return;
+    float m1 = NEG_BIG, l1 = 0.f, m2 = NEG_BIG, l2 = 0.f;
+    for (int p = lane; p < n_parts; p += 64) {
+        const f32x4 s = *reinterpret_cast<const f32x4*>(parts + ((int64_t)p * B + q) * 4);
+        merge_ml(m1, l1, s.x, s.y);
+        merge_ml(m2, l2, s.z, s.w);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        merge_ml(m1, l1, __shfl_xor(m1, off), __shfl_xor(l1, off));
+        merge_ml(m2, l2, __shfl_xor(m2, off), __shfl_xor(l2, off));
+    }
+    if (lane == 0) {
+        f32x4 o = {m1, l1, m2, l2};
+        *reinterpret_cast<f32x4*>(out + q * 4) = o;
+    }
 }
 
 // top-k of n_cand candidates per query (values desc, ties -> lower index), k <= 16.

@@ -19,6 +19,20 @@
 using namespace range_hip;
 using namespace range_host;
 
+// geometry of the small-batch top-k stream kernel (waves per workgroup, key tiles per wave ring)
+// (tools/topk_stream_sweep.sh: 4 x 2 is the fastest; fewer waves with deeper rings lose more in
+// per-wave list maintenance than they gain in bytes in flight)
+// top-k batches up to this size keep per-lane lists inside pass 1 (scan_stats_kernel<.., true>),
+// larger ones select from the kept logits.  Measured (tools/topk_total_time.py): the selection
+// wins at every batch size, so the in-scan lists only serve contexts that cannot keep logits.
+#ifndef RANGE_TOPK_INSCAN_MAX
+#define RANGE_TOPK_INSCAN_MAX 0
+#endif
+#ifndef RANGE_TOPKS_WAVES
+#define RANGE_TOPKS_WAVES 4
+#define RANGE_TOPKS_DEPTH 2
+#endif
+
 struct range_ctx {
     int device = 0;
     int n_cu = 256;
@@ -38,7 +52,7 @@ struct range_ctx {
     DevBuf<float> ws_stats_parts, ws_slabs, ws_stats, ws_ehat32, ws_xq, ws_partial, ws_cand_val;
     // logits kept by the last range_scan_stats(keep_logits = 1): kept_B queries x kept_blocks
     // bank blocks, 1 KB tiles (attend_kernels.h: logit_tile); kept_B == 0: nothing kept
-    DevBuf<float> ws_logits;
+    DevBuf<float> ws_logits, ws_rowmax, ws_theta;
     int64_t kept_B = 0;
     int32_t kept_blocks = 0;
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
@@ -163,6 +177,7 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.cand_idx = nullptr;
     a.logits = nullptr;
     a.qt_offset = 0;
+    a.rowmax = nullptr;
     if (!pass1) {
         c->last_qtiles = a.n_qtiles;
         c->last_splits = a.n_splits;
@@ -463,31 +478,44 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
-    // top-k candidates cost 512 B per (query, split) and are merged by one thread per query:
-    // keep the split count low in that variant
-    // (small batches are HBM-bound: many splits so that every CU streams a share of the keys)
-    const int few = B <= 4 * QTILE;
-    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true,
-                            topk > 0 ? (few ? 64 : 16) : (few ? 2048 : 128));
-    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
-    a.out = c->ws_stats_parts.p;
     c->kept_B = 0;
-    if (keep_logits && topk == 0 && c->allow_keep) {
-        // 4 B per (query, bank row) of this context's shard; skipped (pass 2 then recomputes)
-        // when that would take more than half of the free device memory
-        const size_t need = (size_t)a.n_qtiles * a.n_blocks * 1024;
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (need <= c->ws_logits.n || need * sizeof(float) <= free_b / 2) {
-            HIP_TRY(c->ws_logits.ensure(need));
-            a.logits = c->ws_logits.p;
-            c->kept_B = B;
-            c->kept_blocks = a.n_blocks;
+    // small batches are HBM-bound: many splits so that every CU streams a share of the keys
+    const bool few = B <= 4 * QTILE;
+    // The logits of this call are written to HBM when the caller asks for them (plain scan) or
+    // when a larger batch wants its top-k: pass 1 then runs WITHOUT the in-loop list maintenance
+    // (which costs more than its MFMAs) and a streaming selection over the kept logits follows.
+    // 4 B per (query, bank row) of this context's shard; not done when that would take more than
+    // half of the free device memory (pass 2 then recomputes, top-k uses the in-scan lists).
+    bool write_logits = c->allow_keep && (topk > 0 ? B > RANGE_TOPK_INSCAN_MAX : keep_logits != 0);
+    const int64_t n_qtiles = (B + QTILE - 1) / QTILE, n_blocks = (c->n_rows + BLK - 1) / BLK;
+    if (write_logits) {
+        const size_t need = (size_t)n_qtiles * n_blocks * 1024;
+        if (need > c->ws_logits.n) {        // (hipMemGetInfo is slow: only when growing)
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            if (need * sizeof(float) <= free_b / 2)
+                HIP_TRY(c->ws_logits.ensure(need));
+            else
+                write_logits = false;
         }
     }
-    if (topk > 0) {
+    const bool topk_from_kept = topk > 0 && write_logits;
+    const bool topk_scan = topk > 0 && !topk_from_kept;
+    // in-scan top-k candidates cost 512 B per (query, split) and are merged by one wave per
+    // query: keep the split count moderate in that variant
+    int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true,
+                            topk_scan ? (few ? 256 : 16) : (few ? 2048 : 128));
+    if (rc) return rc;
+    if (write_logits) a.logits = c->ws_logits.p;
+    if (topk_from_kept) {
+        HIP_TRY(c->ws_rowmax.ensure((size_t)a.n_splits * B * 4));
+        HIP_TRY(c->ws_theta.ensure((size_t)B));
+        a.rowmax = c->ws_rowmax.p;
+    }
+    HIP_TRY(c->ws_stats_parts.ensure((size_t)a.n_splits * B * 4));
+    a.out = c->ws_stats_parts.p;
+    if (topk_scan) {
         HIP_TRY(c->ws_cand_val.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
         HIP_TRY(c->ws_cand_idx.ensure((size_t)a.n_splits * B * 4 * MAX_TOPK));
         a.cand_val = c->ws_cand_val.p;
@@ -503,21 +531,48 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     } while (0)
     {
         ProfScope ps(c, RANGE_PROF_SCAN_STATS, s);
-        if (geo && topk) RANGE_SCAN_LAUNCH(true, true);
+        if (geo && topk_scan) RANGE_SCAN_LAUNCH(true, true);
         else if (geo) RANGE_SCAN_LAUNCH(true, false);
-        else if (topk) RANGE_SCAN_LAUNCH(false, true);
+        else if (topk_scan) RANGE_SCAN_LAUNCH(false, true);
         else RANGE_SCAN_LAUNCH(false, false);
     }
 #undef RANGE_SCAN_LAUNCH
     HIP_TRY(hipGetLastError());
+    if (a.logits && keep_logits) {
+        c->kept_B = B;
+        c->kept_blocks = a.n_blocks;
+    }
     const int tpb = 256;
-    hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(tpb), 0, s,
-                       c->ws_stats_parts.p, a.n_splits, B, stats);
+    if (a.n_splits > 32)
+        hipLaunchKernelGGL(merge_stats_wave_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                           c->ws_stats_parts.p, a.n_splits, B, stats);
+    else
+        hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(tpb), 0, s,
+                           c->ws_stats_parts.p, a.n_splits, B, stats);
     HIP_TRY(hipGetLastError());
-    if (topk > 0) {
-        hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,
-                           c->ws_cand_val.p, c->ws_cand_idx.p, (const int64_t*)nullptr, a.n_splits,
-                           B, 4 * MAX_TOPK, topk, c->row_offset, topk_val, topk_idx);
+    if (topk_from_kept) {
+        // enough waves to fill the chip: (B/16 wave slots) x chunks of bank blocks
+        const int64_t n_slots = (B + 15) / 16;
+        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(
+            std::min<int64_t>(64, a.n_blocks / 32 > 0 ? a.n_blocks / 32 : 1),
+            ((int64_t)16 * c->n_cu + n_slots - 1) / n_slots));
+        HIP_TRY(c->ws_cand_val.ensure((size_t)n_chunks * B * MAX_TOPK));
+        HIP_TRY(c->ws_cand_idx.ensure((size_t)n_chunks * B * MAX_TOPK));
+        hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                           c->ws_rowmax.p, a.n_splits, B, c->ws_theta.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(topk_from_logits_kernel, dim3((unsigned)((n_slots + 3) / 4), (unsigned)n_chunks),
+                           dim3(256), 0, s, c->ws_logits.p, a.n_blocks, B, c->n_rows, n_chunks,
+                           c->ws_theta.p, c->ws_cand_val.p, c->ws_cand_idx.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                           c->ws_cand_val.p, c->ws_cand_idx.p, n_chunks, B, MAX_TOPK, topk,
+                           c->row_offset, topk_val, topk_idx);
+        HIP_TRY(hipGetLastError());
+    } else if (topk_scan) {
+        hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                           c->ws_cand_val.p, c->ws_cand_idx.p, a.n_splits, B, 4 * MAX_TOPK, topk,
+                           c->row_offset, topk_val, topk_idx);
         HIP_TRY(hipGetLastError());
     }
     return RANGE_OK;
@@ -533,8 +588,10 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     hipStream_t s = (hipStream_t)stream;
     const int n_groups = (int)((B + 15) / 16);
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
-    // one candidate list per workgroup, one merge thread per list (<= 512)
-    const int n_wg = std::max(1, std::min(c->n_cu, (n_blocks + 3) / 4));
+    // one workgroup per CU (its rings fill the LDS), one candidate list per workgroup, one merge
+    // thread per list (<= 512)
+    constexpr int TS_WAVES = RANGE_TOPKS_WAVES, TS_DEPTH = RANGE_TOPKS_DEPTH;
+    const int n_wg = std::max(1, std::min(c->n_cu, (n_blocks + TS_WAVES - 1) / TS_WAVES));
     HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_wg * 16 * MAX_TOPK));
     TopkStreamArgs a{};
     a.keys = c->d_keys.p;
@@ -543,12 +600,13 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     a.B = B;
     a.n_valid = c->n_rows;
     a.n_blocks = n_blocks;
-    int rc = set_dyn_lds(topk_stream_kernel, TOPKS_LDS_BYTES);
+    constexpr int lds = topks_lds_bytes<TS_WAVES, TS_DEPTH>();
+    int rc = set_dyn_lds(topk_stream_kernel<TS_WAVES, TS_DEPTH>, lds);
     if (rc) return rc;
     {
         ProfScope ps(c, RANGE_PROF_SCAN_STATS, s);
-        hipLaunchKernelGGL(topk_stream_kernel, dim3((unsigned)n_wg, (unsigned)n_groups), dim3(256),
-                           TOPKS_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((topk_stream_kernel<TS_WAVES, TS_DEPTH>), dim3((unsigned)n_wg, (unsigned)n_groups),
+                           dim3(TS_WAVES * 64), lds, s, a);
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)B), dim3(n_wg > 256 ? 512 : 256), 0, s, c->ws_cand_keys.p, n_wg, B,

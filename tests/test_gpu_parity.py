@@ -167,7 +167,8 @@ def _topk_ok(ti, tv, s64, k):
     return int(bad.sum())
 
 
-@pytest.mark.parametrize("N,B,k", [(500, 33, 16), (1537, 64, 5), (20000, 200, 16), (9, 3, 4)])
+@pytest.mark.parametrize("N,B,k", [(500, 33, 16), (1537, 64, 5), (20000, 200, 16), (9, 3, 4),
+                                   (3000, 300, 16), (20000, 1100, 7), (700, 257, 16)])
 def test_topk_vs_oracle(N, B, k):
     bank, obank, w, enc, q, e = _synthetic_case(N, B)
     eng = _engine(None, bank, row_offset=0)
@@ -511,8 +512,22 @@ def test_attend_kept_is_bit_identical(N, B):
         eng.attend_kept(32, xq[32:], 12.0, 40.0, 0.5, st15[32:])        # not on a query tile
     with pytest.raises(_native.RangeNativeError):
         eng.attend_kept(0, torch.cat([xq, xq]), 12.0, 40.0, 0.5, torch.cat([st15, st15]))
-    _, tv, ti = eng.scan_stats(e32, xq, 12.0, 0.0, topk=4, keep_logits=True)   # top-k variant: no keep
+    # with top-k: the selection runs over the kept logits and leaves them for pass 2
+    st_k, tv, ti = eng.scan_stats(e32, xq, 12.0, 40.0, topk=4, keep_logits=True)
+    assert eng.kept_queries() == B
+    assert torch.equal(eng.attend_kept(0, xq, 12.0, 40.0, 0.5, st_k),
+                       eng.attend(e32, xq, 12.0, 40.0, 0.5, st_k))
+    eng.scan_stats(e32, xq, 12.0, 40.0, topk=4)              # not asked to keep: nothing advertised
     assert eng.kept_queries() == 0
+    # the selection over kept logits and the in-scan lists give the same top-k
+    os.environ["RANGE_KEEP_LOGITS"] = "0"
+    try:
+        eng0 = _engine(enc, bank)
+    finally:
+        del os.environ["RANGE_KEEP_LOGITS"]
+    _, tv0, ti0 = eng0.scan_stats(e32, xq, 12.0, 40.0, topk=4)
+    assert eng0.kept_queries() == 0
+    assert torch.equal(ti, ti0) and torch.equal(tv, tv0)
 
 
 def test_forward_without_kept_logits_is_identical(tmp_path, monkeypatch):
