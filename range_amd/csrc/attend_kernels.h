@@ -1459,6 +1459,7 @@ __global__ void finalize_kernel(const float* parts, int n_parts, const double* e
         const int64_t off = q * 256 + c;
         const int64_t stride = B * 256;
         f32x4 s = reinterpret_cast<const f32x4*>(parts)[off];
+#pragma unroll 8   // loads of 8 parts in flight; the additions keep their order
         for (int p = 1; p < n_parts; ++p) s += reinterpret_cast<const f32x4*>(parts)[(int64_t)p * stride + off];
         o[0] = (double)s.x; o[1] = (double)s.y; o[2] = (double)s.z; o[3] = (double)s.w;
     } else {

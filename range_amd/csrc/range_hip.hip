@@ -166,8 +166,10 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.n_blocks = (int32_t)((c->n_rows + BLK - 1) / BLK);
     a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
     // pass 1 writes 16 B per (query, split): many splits are free; pass 2 writes a 4 KB row
+    // (a small batch may split pass 2 further, until every CU has a workgroup)
     a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 4, p1_max_splits)
-                       : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1, 32);
+                       : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1,
+                                       std::max(32, std::min(512, (c->n_cu + a.n_qtiles - 1) / a.n_qtiles)));
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
     a.beta = 1.f;
