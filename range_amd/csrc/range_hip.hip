@@ -96,7 +96,8 @@ namespace {
 // round is best filled (e.g. 157 query tiles x 13 splits = 2041 workgroups = 7.97 rounds of 256),
 // preferring fewer splits (less partial-result traffic) on near-ties.  wg_per_cu: 1 for pass 2
 // (512 registers, 129 KB LDS), 4 for pass 1 (33 KB LDS, <= 128 VGPRs).
-int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits) {
+int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits,
+                  double split_cost = 0.002) {
     const double slots = (double)n_cu * wg_per_cu;
     const int cap = std::max(1, std::min(max_splits, n_blocks / 4));   // >= 4 blocks per split
     // small batches: first of all give every slot a workgroup
@@ -108,7 +109,7 @@ int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_s
         const double rounds = std::ceil(total / slots);
         double score = total / (rounds * slots);            // fill of the rounds
         if (rounds < 4) score *= 0.85 + 0.0375 * rounds;    // few rounds: ragged finish hurts more
-        score -= 0.002 * (ns - ns_min);                     // partial-result traffic
+        score -= split_cost * (ns - ns_min);                // partial-result traffic
         if (score > best_score) { best_score = score; best = ns; }
         if (ns - ns_min > 64) break;
     }
@@ -166,10 +167,14 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.n_blocks = (int32_t)((c->n_rows + BLK - 1) / BLK);
     a.n_qtiles = (int32_t)((B + QTILE - 1) / QTILE);
     // pass 1 writes 16 B per (query, split): many splits are free; pass 2 writes a 4 KB row
-    // (a small batch may split pass 2 further, until every CU has a workgroup)
+    // (a small batch may split pass 2 further, until every CU has a workgroup).  Every extra
+    // split of pass 2 writes and re-reads a 4 KB row per query: 8 KB at ~4 TB/s against the
+    // query's MFMA time n_rows * 2054 FLOP / 140 TFLOP/s, i.e. 140 / n_rows of the launch - small
+    // for the whole bank on one GPU, 1 % per split for a 12 500-row shard.
     a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 4, p1_max_splits)
                        : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1,
-                                       std::max(32, std::min(512, (c->n_cu + a.n_qtiles - 1) / a.n_qtiles)));
+                                       std::max(32, std::min(512, (c->n_cu + a.n_qtiles - 1) / a.n_qtiles)),
+                                       std::max(0.001, 140.0 / (double)c->n_rows));
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
     a.beta = 1.f;
