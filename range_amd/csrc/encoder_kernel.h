@@ -48,6 +48,7 @@ struct EncArgs {
     int32_t H;
     int32_t kp0_total;      // k-step PAIRS (8 features) of the padded, permuted first-layer K
     int32_t lds_main_doubles;
+    int32_t n_wg32;         // workgroups [0, n_wg32) take 32 queries each, the rest 16
     const int32_t* slot_base;   // [n_slots+1] padded feature offsets (multiples of 8)
     const double* coefA;        // [L*L] at l*L+m : a(l,m)            (0 for l<=m)
     const double* coefB;        // [L*L] at l*L+m : a(l,m)*b(l,m)
@@ -83,10 +84,10 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // kp_rot rotates the order in which the pairs are visited (pair index = (i + kp_rot) mod kpairs):
 // every workgroup streams the SAME weights, and without a per-workgroup rotation they all ask the
 // same L2 lines at the same moment.
-template <int NTW>
+template <int NTW, int QT>
 __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, int kpairs,
                                             int64_t kp_stride, int kp_rot, int lane,
-                                            f64x4 (&acc)[2][NTW]) {
+                                            f64x4 (&acc)[QT][NTW]) {
     auto rot = [&](int i) __attribute__((always_inline)) {
         i += kp_rot;
         return i >= kpairs ? i - kpairs : i;
@@ -106,9 +107,9 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
             const double a00 = lds[frag_addr(ks, 0, lane)];
-            const double a01 = lds[frag_addr(ks, 1, lane)];
+            const double a01 = QT > 1 ? lds[frag_addr(ks, 1, lane)] : 0.0;
             const double a10 = lds[frag_addr(ks + 1, 0, lane)];
-            const double a11 = lds[frag_addr(ks + 1, 1, lane)];
+            const double a11 = QT > 1 ? lds[frag_addr(ks + 1, 1, lane)] : 0.0;
             f64x2 b[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) b[i] = bq[d][i];
@@ -119,12 +120,12 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, b[i].x, acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b[i].x, acc[1][i], 0, 0, 0);
+                if (QT > 1) acc[QT - 1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b[i].x, acc[QT - 1][i], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, b[i].y, acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b[i].y, acc[1][i], 0, 0, 0);
+                if (QT > 1) acc[QT - 1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b[i].y, acc[QT - 1][i], 0, 0, 0);
             }
         }
     }
@@ -135,30 +136,30 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
             const double a00 = lds[frag_addr(ks, 0, lane)];
-            const double a01 = lds[frag_addr(ks, 1, lane)];
+            const double a01 = QT > 1 ? lds[frag_addr(ks, 1, lane)] : 0.0;
             const double a10 = lds[frag_addr(ks + 1, 0, lane)];
-            const double a11 = lds[frag_addr(ks + 1, 1, lane)];
+            const double a11 = QT > 1 ? lds[frag_addr(ks + 1, 1, lane)] : 0.0;
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, bq[d][i].x, acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, bq[d][i].x, acc[1][i], 0, 0, 0);
+                if (QT > 1) acc[QT - 1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, bq[d][i].x, acc[QT - 1][i], 0, 0, 0);
                 acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, bq[d][i].y, acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, bq[d][i].y, acc[1][i], 0, 0, 0);
+                if (QT > 1) acc[QT - 1][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, bq[d][i].y, acc[QT - 1][i], 0, 0, 0);
             }
         }
     }
 }
 
 // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
-template <int NTW>
+template <int NTW, int QT>
 __device__ __forceinline__ void store_act(double* lds, const double* bias, double w0, int wave,
-                                          int lane, f64x4 (&acc)[2][NTW]) {
+                                          int lane, f64x4 (&acc)[QT][NTW]) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int n = (wave * NTW + i) * 16 + (lane & 15);
         const double bn = bias[n];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = qt * 16 + (lane >> 4) + 4 * r;
@@ -167,15 +168,23 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
     }
 }
 
-template <int NT>   // NT = H / 64 : n-tiles of 16 hidden columns per wave
-__global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// NT = H / 64.  NW waves per workgroup (4 or 16) share the H/16 n-tiles of 16 hidden columns:
+// NTW = 4*NT/NW per wave (and 16/NW of the 16 output n-tiles).  Sixteen waves (four per SIMD)
+// are what the float64 MFMA pipe wants (tools/micro/mfma_f64_peak.hip: 36 TFLOP/s with 1-2 waves
+// per SIMD, 47-49 with 3 or more); they need H to be a multiple of 256.
+// QT = 16-query tiles of the workgroup: 2 (32 queries) or 1.  Workgroups are equal-cost, so a
+// batch that needs 1.2 rounds of 32-query workgroups pays for 2; the host then gives the LAST
+// round half-size workgroups (EncArgs::n_wg32), which finish in about half the time.
+template <int NT, int NW, int QT>
+__device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem) {
+    constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
+    constexpr int EW = 16 / NW;        // output n-tiles per wave
+    static_assert(NTW * NW == 4 * NT && EW * NW == 16, "n-tiles must divide among the waves");
     double* lds = reinterpret_cast<double*>(smem);
-    double* red = lds + a.lds_main_doubles;      // [4 waves][32 queries]
+    double* red = lds + a.lds_main_doubles;      // [NW waves][32 queries]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t q0 = (int64_t)blockIdx.x * ENC_QTILE;
     const double DEG = 3.14159265358979323846 / 180.0;
 
     // ---- SH generator state: thread = (query gq, slot-in-round gslot); threads 128..255 idle
@@ -189,9 +198,11 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
         sx = sin(theta);
     }
 
-    f64x4 acc[2][NT];
+    f64x4 acc[QT][NTW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt][i] = f64x4{0, 0, 0, 0};
 
     const int L = a.L;
     for (int rnd_i = 0; rnd_i < a.n_rounds; ++rnd_i) {
@@ -233,8 +244,8 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
         }
         __syncthreads();
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
-                          ((int64_t)(wave * NT) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
-        gemm_kpairs<NT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
+                          ((int64_t)(wave * NTW) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
+        gemm_kpairs<NTW, QT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
     }
 
     // ---- hidden layers: h = sin(w0 * (acc + b)), w0 = 30 on the first layer only
@@ -242,38 +253,42 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
     const int kpH = a.H >> 3;
     for (int layer = 0; layer < a.n_layers; ++layer) {
         __syncthreads();   // all waves finished reading the previous operand
-        store_act<NT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
+        store_act<NTW, QT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
         __syncthreads();
         if (layer + 1 < a.n_layers) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) { acc[0][i] = f64x4{0, 0, 0, 0}; acc[1][i] = f64x4{0, 0, 0, 0}; }
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) acc[qt][i] = f64x4{0, 0, 0, 0};
             const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[layer + 1]) +
-                              ((int64_t)(wave * NT) * kpH) * 64 + lane;
-            gemm_kpairs<NT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, acc);
+                              ((int64_t)(wave * NTW) * kpH) * 64 + lane;
+            gemm_kpairs<NTW, QT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, acc);
         }
     }
 
     // ---- last layer (Identity activation, location_encoder.py:95-96, 112): 256 outputs,
-    //      4 n-tiles per wave
-    f64x4 ae[2][4];
+    //      EW n-tiles per wave
+    f64x4 ae[QT][EW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ae[0][i] = f64x4{0, 0, 0, 0}; ae[1][i] = f64x4{0, 0, 0, 0}; }
+    for (int i = 0; i < EW; ++i)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) ae[qt][i] = f64x4{0, 0, 0, 0};
     {
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) +
-                          ((int64_t)(wave * 4) * kpH) * 64 + lane;
-        gemm_kpairs<4>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, ae);
+                          ((int64_t)(wave * EW) * kpH) * 64 + lane;
+        gemm_kpairs<EW, QT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, ae);
     }
     const double* bl = a.bias[a.n_layers];
-    double ss[2][4];
+    double ss[QT][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ss[qt][r] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double bn = bl[(wave * 4 + i) * 16 + (lane & 15)];
+    for (int i = 0; i < EW; ++i) {
+        const double bn = bl[(wave * EW + i) * 16 + (lane & 15)];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ae[qt][i][r] += bn;
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
     }
     // ---- L2 norm over the 256 outputs of each query (range.py:212)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v = ss[qt][r];
@@ -291,16 +306,19 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
         }
     __syncthreads();
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ql = qt * 16 + (lane >> 4) + 4 * r;
-            const double nrm = sqrt(red[ql] + red[32 + ql] + red[64 + ql] + red[96 + ql]);
+            double sq = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sq += red[w * 32 + ql];
+            const double nrm = sqrt(sq);
             const int64_t q = q0 + ql;
             if (q < a.B) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = (wave * 4 + i) * 16 + (lane & 15);
+                for (int i = 0; i < EW; ++i) {
+                    const int n = (wave * EW + i) * 16 + (lane & 15);
                     const double e = ae[qt][i][r] / nrm;
                     if (a.eraw64) a.eraw64[q * ENC_EMBED + n] = ae[qt][i][r];
                     a.ehat64[q * ENC_EMBED + n] = e;
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
             }
         }
     // ---- query unit vector: float64 trig, then .float()  (range.py:225-231, utils.py:11-16)
-    if (tid < ENC_QTILE && q0 + tid < a.B) {
+    if (tid < 16 * QT && q0 + tid < a.B) {
         const int64_t q = q0 + tid;
         const double lon = a.lonlat[2 * q] * 3.14159265358979323846 / 180.0;
         const double lat = a.lonlat[2 * q + 1] * 3.14159265358979323846 / 180.0;
@@ -317,6 +335,14 @@ __global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
         float4 o = make_float4((float)(cl * cos(lon)), (float)(cl * sin(lon)), (float)sin(lat), 0.f);
         *reinterpret_cast<float4*>(a.xq + q * 4) = o;
     }
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void encoder_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (b < a.n_wg32) encoder_body<NT, NW, 2>(a, (int64_t)b * 32, smem);
+    else encoder_body<NT, NW, 1>(a, (int64_t)a.n_wg32 * 32 + (int64_t)(b - a.n_wg32) * 16, smem);
 }
 
 }  // namespace range_hip

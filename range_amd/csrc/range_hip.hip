@@ -22,6 +22,10 @@ using namespace range_host;
 // geometry of the small-batch top-k stream kernel (waves per workgroup, key tiles per wave ring)
 // (tools/topk_stream_sweep.sh: 4 x 2 is the fastest; fewer waves with deeper rings lose more in
 // per-wave list maintenance than they gain in bytes in flight)
+// waves per encoder workgroup when the hidden width is a multiple of 256 (4 or 16)
+#ifndef RANGE_ENC_WAVES
+#define RANGE_ENC_WAVES 16
+#endif
 // top-k batches up to this size keep per-lane lists inside pass 1 (scan_stats_kernel<.., true>),
 // larger ones select from the kept logits.  Measured (tools/topk_total_time.py): the selection
 // wins at every batch size, so the in-scan lists only serve contexts that cannot keep logits.
@@ -123,26 +127,41 @@ int set_dyn_lds(K kernel, size_t bytes) {
     return RANGE_OK;
 }
 
-int launch_encoder(range_ctx* c, const EncArgs& a, hipStream_t s) {
-    const int grid = (int)((a.B + ENC_QTILE - 1) / ENC_QTILE);
+int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
+    EncArgs a = a_in;
+    // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
+    // them would be less than half full, it is run with 16-query workgroups instead (about half
+    // the time each): 10 000 queries = 256 x 32 + 113 x 16 instead of 313 x 32.
+    const int64_t wg32 = (a.B + ENC_QTILE - 1) / ENC_QTILE;
+    const int64_t full_rounds = wg32 / c->n_cu;
+    const int64_t rem = a.B - full_rounds * c->n_cu * ENC_QTILE;      // queries after the full rounds
+    int grid;
+    if (full_rounds > 0 && rem > 0 && rem <= (int64_t)16 * c->n_cu) {
+        a.n_wg32 = (int32_t)(full_rounds * c->n_cu);
+        grid = a.n_wg32 + (int)((rem + 15) / 16);
+    } else {
+        a.n_wg32 = (int32_t)wg32;
+        grid = (int)wg32;
+    }
     const size_t lds = c->enc_lds_bytes;
-#define RANGE_ENC_CASE(NT)                                                          \
-    case NT: {                                                                      \
-        int rc = set_dyn_lds(encoder_kernel<NT>, lds);                              \
-        if (rc) return rc;                                                          \
-        hipLaunchKernelGGL(encoder_kernel<NT>, dim3(grid), dim3(256), lds, s, a);   \
-        break;                                                                      \
+#define RANGE_ENC_CASE(NT, NW)                                                              \
+    case NT: {                                                                              \
+        int rc = set_dyn_lds(encoder_kernel<NT, NW>, lds);                                  \
+        if (rc) return rc;                                                                  \
+        hipLaunchKernelGGL((encoder_kernel<NT, NW>), dim3(grid), dim3(NW * 64), lds, s, a); \
+        break;                                                                              \
     }
     ProfScope ps(c, RANGE_PROF_ENCODER, s);
+    // 16 waves per workgroup where the hidden width allows (multiples of 256), else 4
     switch (a.H / 64) {
-        RANGE_ENC_CASE(1)
-        RANGE_ENC_CASE(2)
-        RANGE_ENC_CASE(3)
-        RANGE_ENC_CASE(4)
-        RANGE_ENC_CASE(5)
-        RANGE_ENC_CASE(6)
-        RANGE_ENC_CASE(7)
-        RANGE_ENC_CASE(8)
+        RANGE_ENC_CASE(1, 4)
+        RANGE_ENC_CASE(2, 4)
+        RANGE_ENC_CASE(3, 4)
+        RANGE_ENC_CASE(4, RANGE_ENC_WAVES)
+        RANGE_ENC_CASE(5, 4)
+        RANGE_ENC_CASE(6, 4)
+        RANGE_ENC_CASE(7, 4)
+        RANGE_ENC_CASE(8, RANGE_ENC_WAVES)
         default:
             return fail(RANGE_ERR_INVALID, "unsupported hidden width %d", a.H);
     }
@@ -282,7 +301,7 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
         max_round = std::max(max_round, slot_base[s1] - slot_base[r * ENC_SLOTS_PER_ROUND]);
     }
     const int lds_main = ENC_QTILE * std::max(max_round, H);
-    const size_t lds_bytes = (size_t)(lds_main + 4 * ENC_QTILE) * sizeof(double);
+    const size_t lds_bytes = (size_t)(lds_main + 16 * ENC_QTILE) * sizeof(double);   // + [<= 16 waves][32] partial norms
     if (lds_bytes > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS (>160 KiB)", lds_bytes);
 
     // ---- recurrence tables (float64)

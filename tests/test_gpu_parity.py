@@ -544,3 +544,18 @@ def test_forward_without_kept_logits_is_identical(tmp_path, monkeypatch):
         outs.append(m(q))
         assert (m.engine.kept_queries() == 333) == (env == "1")
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B", [8192 + 1, 10000, 8192 + 4096, 8192 + 4097, 3 * 8192 + 77])
+def test_encoder_large_batch_geometry(B):
+    """Batches beyond one round of 32-query workgroups: the last round may run as 16-query
+    workgroups (10 000 = 256 x 32 + 113 x 16); every query must still come out right, in order."""
+    w, enc = _params(10, 256, 2, 5)              # H = 256: the 16-wave kernel
+    eng = _engine(enc)
+    q = synth.make_queries(B, seed=B, lat_max=60.0)
+    e64, e32, xq = eng.encode(_dev(q))
+    ref = O.encode(q, w, 10)
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    np.testing.assert_allclose(e64.cpu().numpy(), ref, rtol=0, atol=2e-12)
+    np.testing.assert_array_equal(e32.cpu().numpy(), e64.cpu().numpy().astype(np.float32))
+    np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1e-7)
