@@ -136,7 +136,11 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     const int64_t full_rounds = wg32 / c->n_cu;
     const int64_t rem = a.B - full_rounds * c->n_cu * ENC_QTILE;      // queries after the full rounds
     int grid;
-    if (full_rounds > 0 && rem > 0 && rem <= (int64_t)16 * c->n_cu) {
+    if (a.B <= (int64_t)16 * c->n_cu) {
+        // a batch that fits in one round either way: half-size workgroups on twice the CUs
+        a.n_wg32 = 0;
+        grid = (int)((a.B + 15) / 16);
+    } else if (full_rounds > 0 && rem > 0 && rem <= (int64_t)16 * c->n_cu) {
         a.n_wg32 = (int32_t)(full_rounds * c->n_cu);
         grid = a.n_wg32 + (int)((rem + 15) / 16);
     } else {
