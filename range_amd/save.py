@@ -43,6 +43,13 @@ class EmbeddingPipeline:
     def run(self, batches: Iterable) -> Iterator[np.ndarray]:
         """``batches`` yields (B,2) coordinate tensors/arrays.  Yields one float64 ndarray
         (B,1280) per batch, in order.  Each yielded array is a fresh host array."""
+        if getattr(self.model, "_model_id", None) is None:
+            # SatCLIP and the training-free coordinate encoders: tiny outputs, no pipeline -
+            # one call per batch like range/utils/save.py:28-30
+            for coords in batches:
+                out = self.model(coords)
+                yield out.cpu().numpy() if torch.is_tensor(out) else np.asarray(out)
+            return
         inflight: List[Tuple[int, int]] = []          # (slot, rows)
         compute = torch.cuda.current_stream(self.device)
         i = 0

@@ -164,3 +164,41 @@ def test_evaluate_npz_drop_in(tmp_path, capsys):
     with pytest.raises(AssertionError):
         ev.evaluate_npz(Namespace(embeddings_dir=str(tmp_path), location_model_name="RANGE+",
                                   task_name="absent"))
+
+
+def test_pipeline_embed_save_probe(tmp_path, capsys):
+    """The reference's two-step workflow end to end on the GPU (range/range.py:281-306):
+    save_embeddings with a RANGE+ model, then evaluate_npz on the files it wrote; the probe's
+    score equals the oracle's on the same files; the plain encoders go through the same driver."""
+    from range_amd import load_model
+    from range_amd.save import save_embeddings
+    ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 2000, 3)
+    rng = np.random.default_rng(12)
+    q = synth.make_queries(2600, seed=41, lat_max=80.0)
+    # synthetic downstream targets that depend smoothly on the location
+    lat, lon = np.deg2rad(q[:, 1]), np.deg2rad(q[:, 0])
+    temp = 25.0 * np.cos(lat) + 3.0 * np.sin(2 * lon) + rng.normal(0, 0.5, q.shape[0])
+    biome = (np.digitize(q[:, 1], [-40, -10, 10, 40]) * 2 + (q[:, 0] > 0)).astype(np.int64)
+
+    def loader(y, a, b, bs=512):
+        return [(torch.from_numpy(q[i:min(i + bs, b)]), torch.from_numpy(y[i:min(i + bs, b)]))
+                for i in range(a, b, bs)]
+
+    emb_dir = str(tmp_path / "emb")
+    for name, kw in (("RANGE+", dict(db_path=db, beta=0.5)), ("Wrap", {})):
+        model = load_model(name, pretrained_path=ck, device="cuda:0", **kw)
+        for task, y in (("temperature", temp), ("biome", biome)):
+            args = Namespace(embeddings_dir=emb_dir, location_model_name=name, task_name=task,
+                             device="cuda:0")
+            save_embeddings(args, loader(y, 0, 2000), loader(y, 2000, 2600), model)
+            score = ev.evaluate_npz(args)
+            tr = np.load(os.path.join(emb_dir, name, task + "_train.npz"))
+            va = np.load(os.path.join(emb_dir, name, task + "_val.npz"))
+            assert tr["embeddings"].shape == (2000, model.location_feature_dim)
+            ref = po.probe(tr["embeddings"], tr["y"], va["embeddings"], va["y"], po.task_kind(task))
+            if task == "biome":
+                assert score == ref["score"] and score > 0.5
+            else:
+                assert abs(score - ref["score"]) < 1e-9 and score > 0.5
+    capsys.readouterr()
