@@ -1394,9 +1394,15 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
                         else if (op == 3) { if (GEO) e2[r] = __builtin_amdgcn_exp2f(e2[r]); }
                         else if (op == 4) e1[r] = ca * e1[r];
                         else if (op == 5) { if (GEO) e1[r] = fmaf(cb, e2[r], e1[r]); }
-                        else w_next[r] = prow[r] < n_left1 ? e1[r] : 0.f;
+                        else w_next[r] = e1[r];
                     }
                 });
+        // pad rows exist only in the bank's last block: their weights are zeroed here, outside
+        // the MFMA gaps (a VALU instruction in a gap costs MFMA issue time)
+        if (n_left1 < BLK) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w_next[r] = prow[r] < n_left1 ? w_next[r] : 0.f;
+        }
         w_cur = w_next;
         vs = vs2;
     }
