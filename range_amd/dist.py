@@ -129,6 +129,55 @@ class ShardedRange:
     __call__ = forward
 
     @torch.no_grad()
+    def sweep(self, lonlat: torch.Tensor, betas) -> torch.Tensor:
+        """RANGE+ embeddings of this rank's queries for several beta values (BASELINE config
+        "beta sweep ... 8xMI355X"): one pass 1, per chunk TWO passes 2 on its kept logits (beta = 1:
+        the semantic retrieval H, beta = 0: the geographic G), two exchanges, then one blend
+        (range.py:238, applied per shard partial - the blend is linear) + finalize per beta.
+        Returns (len(betas), B, 1280) float64 on the device."""
+        if self.tau_geo <= 0.0:
+            raise ValueError("sweep() is defined for RANGE+ only")
+        betas = [float(b) for b in betas]
+        W, B = self.world, lonlat.shape[0]
+        e64, e32_all, xq_all = self._gather_queries(lonlat)
+        chunks = self._chunk_bounds(B)
+        if len(chunks) > 1:
+            e32_v = e32_all.reshape(W, B, -1)
+            xq_v = xq_all.reshape(W, B, -1)
+            e32_all = torch.cat([e32_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+            xq_all = torch.cat([xq_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+        stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
+                                             keep_logits=True)
+        kept = self.engine.kept_queries() == W * B
+        stats = self.engine.merge_stats(self._gather(stats_local))
+        pending = []
+        for lo, hi in chunks:
+            first, n = W * lo, W * (hi - lo)
+            sl = slice(first, first + n)
+            parts = []
+            for b in (1.0, 0.0):
+                if kept:
+                    parts.append(self.engine.attend_kept(first, xq_all[sl], self.tau_sem,
+                                                         self.tau_geo, b, stats[sl]))
+                else:
+                    parts.append(self.engine.attend(e32_all[sl], xq_all[sl], self.tau_sem,
+                                                    self.tau_geo, b, stats[sl]))
+            recv = [torch.empty_like(p) for p in parts]
+            works = [dist.all_to_all_single(r, p, group=self.group, async_op=True)
+                     for r, p in zip(recv, parts)]
+            pending.append((works, recv, parts, lo, hi))
+        out = torch.empty((len(betas), B, e64.shape[1] + 1024), dtype=torch.float64,
+                          device=e64.device)
+        for works, (rH, rG), parts, lo, hi in pending:
+            for w_ in works:
+                w_.wait()
+            e = e64[lo:hi].contiguous()
+            for j, b in enumerate(betas):
+                mix = self.engine.blend(rG, rH, b)                   # (W*n, 1024): per-shard partials
+                out[j, lo:hi] = self.engine.finalize(mix.reshape(W, hi - lo, mix.shape[1]), e)
+        return out
+
+    @torch.no_grad()
     def topk(self, lonlat: torch.Tensor, k: int = 16):
         """Global top-k (semantic cosine similarity) for this rank's queries: per-shard top-k,
         one all-gather of the candidates, k-way merge."""

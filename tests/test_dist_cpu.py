@@ -81,6 +81,9 @@ class OracleShardEngine:
         assert first % 64 == 0 and first + xq.shape[0] <= self._kept.shape[0]
         return self.attend(self._kept[first:first + xq.shape[0]], xq, tau_sem, tau_geo, beta, stats)
 
+    def blend(self, G, H, beta):
+        return ((1.0 - beta) * G.double() + beta * H.double()).float()
+
     def finalize(self, partials, e64):
         acc = partials[0].clone()
         for p in partials[1:]:
@@ -125,6 +128,14 @@ def _worker(rank, world, port, N, B, L, H, ret):
             ref = O.forward(q, w, L, full, name, beta)      # unsharded oracle, own queries
             err = float(np.abs(out - ref).max())
             assert out.shape == (B, 1280) and err < 1e-5, (name, beta, err)   # f32 op-order noise of the reference
+        # beta sweep: one scan, H and G once, every beta from them
+        model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5, n_chunks=2)
+        model.min_chunk = 2
+        betas = (0.0, 0.25, 1.0)
+        sw = model.sweep(torch.from_numpy(q), betas).numpy()
+        for j, b in enumerate(betas):
+            err = float(np.abs(sw[j] - O.forward(q, w, L, full, "RANGE+", b)).max())
+            assert sw.shape == (3, B, 1280) and err < 1e-5, (b, err)
         model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5)
         tv, ti = model.topk(torch.from_numpy(q), 8)
         s, _ = O.logits64(O.encode(q, w, L), q, full)

@@ -336,6 +336,11 @@ def test_sharded_path_over_rccl_world1(tmp_path):
         tv, ti = ShardedRange(eng, "RANGE+", 0.5).topk(x, 8)
         s, _ = O.logits64(e, q, obank)
         _topk_ok(ti.cpu().numpy(), tv.cpu().numpy(), s, 8)
+        model = ShardedRange(eng, "RANGE+", 0.5, n_chunks=2)
+        model.min_chunk = 16
+        sw = model.sweep(x, (0.0, 0.5, 1.0)).cpu().numpy()
+        for j, b in enumerate((0.0, 0.5, 1.0)):
+            np.testing.assert_allclose(sw[j], O.forward(q, w, 10, obank, "RANGE+", b), rtol=0, atol=2e-5)
     finally:
         dist.destroy_process_group()
 
