@@ -59,12 +59,33 @@ class ShardedRange:
         self.rank = dist.get_rank(group)
         self.n_chunks = n_chunks   # None: 4 chunks when there is a peer to exchange with
 
+    def _staged(self, t: torch.Tensor) -> bool:
+        """Device tensors over the gloo backend (several ranks sharing one GPU in tests, or a box
+        without RCCL): the collective runs on host copies.  RCCL moves device memory directly."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         # concatenation form (W*n, ...): accepted by both the RCCL and the gloo backend
+        src = t.contiguous()
+        if self._staged(t):
+            src = src.cpu()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                          device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out.reshape((self.world,) + tuple(t.shape))
+                          device=src.device)
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.to(t.device).reshape((self.world,) + tuple(t.shape))
+
+    def _all_to_all(self, part: torch.Tensor):
+        """Start the exchange of a chunk's partials; returns (work, getter of the received tensor)."""
+        if self._staged(part):
+            src = part.cpu()
+            recv = torch.empty_like(src)
+            work = dist.all_to_all_single(recv, src, group=self.group, async_op=True)
+            return work, (lambda: recv.to(part.device)), src
+        recv = torch.empty_like(part)
+        # one direct transfer per peer; asynchronous, so that the exchange of this chunk
+        # overlaps pass 2 of the next
+        work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
+        return work, (lambda: recv), part
 
     def _gather_queries(self, lonlat: torch.Tensor):
         e64, e32, xq = self.engine.encode(lonlat)
@@ -114,14 +135,12 @@ class ShardedRange:
                 part = self.engine.attend(e32_all[first:first + n], xq_all[first:first + n],
                                           self.tau_sem, self.tau_geo, self.beta,
                                           stats[first:first + n])
-            recv = torch.empty_like(part)
-            # one direct transfer per peer; asynchronous, so that the exchange of this chunk
-            # overlaps pass 2 of the next
-            work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
-            pending.append((work, recv, part, lo, hi))
+            work, get, keep = self._all_to_all(part)
+            pending.append((work, get, keep, lo, hi))
         outs = []
-        for work, recv, part, lo, hi in pending:
+        for work, get, keep, lo, hi in pending:
             work.wait()
+            recv = get()
             outs.append(self.engine.finalize(recv.reshape(W, hi - lo, recv.shape[1]),
                                              e64[lo:hi].contiguous()))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
@@ -162,15 +181,14 @@ class ShardedRange:
                 else:
                     parts.append(self.engine.attend(e32_all[sl], xq_all[sl], self.tau_sem,
                                                     self.tau_geo, b, stats[sl]))
-            recv = [torch.empty_like(p) for p in parts]
-            works = [dist.all_to_all_single(r, p, group=self.group, async_op=True)
-                     for r, p in zip(recv, parts)]
-            pending.append((works, recv, parts, lo, hi))
+            ex = [self._all_to_all(p) for p in parts]
+            pending.append((ex, lo, hi))
         out = torch.empty((len(betas), B, e64.shape[1] + 1024), dtype=torch.float64,
                           device=e64.device)
-        for works, (rH, rG), parts, lo, hi in pending:
-            for w_ in works:
-                w_.wait()
+        for ex, lo, hi in pending:
+            for work, _, _ in ex:
+                work.wait()
+            rH, rG = ex[0][1](), ex[1][1]()
             e = e64[lo:hi].contiguous()
             for j, b in enumerate(betas):
                 mix = self.engine.blend(rG, rH, b)                   # (W*n, 1024): per-shard partials
