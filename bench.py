@@ -96,14 +96,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    dev = torch.device("cuda", local)
+    # RANGE_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives are staged through the host; the timing means nothing)
+    backend = os.environ.get("RANGE_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     sharded = world > 1 or a.force_sharded
     if sharded:
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, shard_rows
-        init_from_env("nccl")
+        init_from_env(backend)
 
     L, H = 40, a.hidden
     N = synth.BANK_ROWS[a.bank]
