@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace range_hip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -414,40 +416,49 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
         const f32x4 sg = c.g;
         if (a.logits)   // keep the tile for pass 2 (the barrier's vmcnt(0) also covers this store)
             *reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
+        // statistics of this tile.  Only the bank's last block can hold pad rows: every other
+        // tile takes the unmasked form (a quarter fewer VALU instructions; pass 1 issues more of
+        // those than MFMAs, and they are not entirely hidden behind the other waves' MFMAs)
         const int64_t row0 = (int64_t)(b0 + t) * BLK;
-        float t1[4], t2[4];
-        bool ok[4];
+        const int n_here = (int)(a.n_valid - row0 < BLK ? a.n_valid - row0 : BLK);   // valid rows
+        auto tile_stats = [&](auto masked_tag) __attribute__((always_inline)) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            float t1[4], t2[4];
+            bool ok[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + pi_row(4 * g + r);
-            ok[r] = row < a.n_valid;
-            t1[r] = ok[r] ? ss[r] * a.k_sem : NEG_BIG;
-            if (GEO) t2[r] = ok[r] ? sg[r] * a.k_geo : NEG_BIG;
-            if (TOPK) { if (ok[r]) tk.push(ss[r], (int32_t)row); }
-        }
-        if (a.rowmax)
-            smax = fmaxf(smax, fmaxf(fmaxf(ok[0] ? ss[0] : -INFINITY, ok[1] ? ss[1] : -INFINITY),
-                                     fmaxf(ok[2] ? ss[2] : -INFINITY, ok[3] ? ss[3] : -INFINITY)));
+            for (int r = 0; r < 4; ++r) {
+                const int pr = pi_row(4 * g + r);
+                ok[r] = !MASKED || pr < n_here;
+                t1[r] = ok[r] ? ss[r] * a.k_sem : NEG_BIG;
+                if (GEO) t2[r] = ok[r] ? sg[r] * a.k_geo : NEG_BIG;
+                if (TOPK) { if (ok[r]) tk.push(ss[r], (int32_t)(row0 + pr)); }
+            }
+            if (a.rowmax)
+                smax = fmaxf(smax, fmaxf(fmaxf(ok[0] ? ss[0] : -INFINITY, ok[1] ? ss[1] : -INFINITY),
+                                         fmaxf(ok[2] ? ss[2] : -INFINITY, ok[3] ? ss[3] : -INFINITY)));
 #ifndef RANGE_EXP_P1_NOVALU
-        {
-            const float mx = fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3]));
-            const float mn = fmaxf(m1, mx);
-            float acc = l1 * __builtin_amdgcn_exp2f(m1 - mn);
+            {
+                const float mx = fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3]));
+                const float mn = fmaxf(m1, mx);
+                float acc = l1 * __builtin_amdgcn_exp2f(m1 - mn);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t1[r] - mn) : 0.f;
-            l1 = acc; m1 = mn;
-        }
-        if (GEO) {
-            const float mx = fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3]));
-            const float mn = fmaxf(m2, mx);
-            float acc = l2 * __builtin_amdgcn_exp2f(m2 - mn);
+                for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t1[r] - mn) : 0.f;
+                l1 = acc; m1 = mn;
+            }
+            if (GEO) {
+                const float mx = fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3]));
+                const float mn = fmaxf(m2, mx);
+                float acc = l2 * __builtin_amdgcn_exp2f(m2 - mn);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t2[r] - mn) : 0.f;
-            l2 = acc; m2 = mn;
-        }
+                for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t2[r] - mn) : 0.f;
+                l2 = acc; m2 = mn;
+            }
 #else
-        l1 += t1[0] + t1[3]; if (GEO) l2 += t2[1];
+            l1 += t1[0] + t1[3]; if (GEO) l2 += t2[1];
 #endif
+        };
+        if (n_here == BLK) tile_stats(std::false_type{});
+        else tile_stats(std::true_type{});
         slot ^= 1;
     }
     // lanes j, j+16, j+32, j+48 hold disjoint row subsets of the same query
