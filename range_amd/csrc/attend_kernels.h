@@ -153,24 +153,17 @@ __device__ __forceinline__ void pin_qfrag(QFrag& f) {
 // One 16-row block of transposed logits.  kt: LDS K tile [16][256] f32 whose 16-byte chunks were
 // permuted at load time (chunk c of row R sits at position c ^ R, see issue_k_tile), which makes
 // the ds_read_b128 below bank-conflict free.  The k index is consumed in a permuted order that is
-// identical for both operands.  Two accumulation chains hide the 40-cycle dependent-MFMA latency;
-// the SAME summation order is used in both passes so pass 2 reproduces pass 1's logits bit for bit.
-// single-instruction f32 add (keeps hipcc from SLP-packing the logit sums into v_pk_add_f32 plus
-// the v_mov shuffles that feed it)
-__device__ __forceinline__ float add1(float x, float y) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
+// identical for both operands.  The 64 MFMAs of a tile form ONE dependent chain on a single
+// accumulator: back-to-back MFMAs that accumulate into their own result issue at full rate on
+// gfx950 (tools/micro/mfma_f32_chains.hip: 99 % with one chain), so the sum needs no VALU adds
+// and every kernel that forms logits (both passes, the top-k scans) gets the same value.
 
-// Accumulators of one transposed logit tile: four independent semantic chains (one per element of
-// the 16-byte K read; a VGPR-accumulator MFMA chain needs ~3 MFMAs of distance to issue back to
-// back) and the geographic tile.  sem(r) is the fixed summation order used by BOTH passes.
+// Accumulators of one transposed logit tile: the semantic chain and the geographic tile.
 struct QKAcc {
-    f32x4 a0, a1, a2, a3, g;
-    __device__ __forceinline__ float sem(int r) const { return (a0[r] + a1[r]) + (a2[r] + a3[r]); }
+    f32x4 a0, g;
+    __device__ __forceinline__ float sem(int r) const { return a0[r]; }
     __device__ __forceinline__ void fence() {   // MFMA results -> VALU readers
-        asm volatile("s_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(g));
+        asm volatile("s_nop 15" : "+v"(a0), "+v"(g));
     }
 };
 
@@ -218,17 +211,11 @@ __device__ __forceinline__ void qk_mfma(const char* kt, const KFirst& first, con
 #else
         if (s < 14) kn2 = *reinterpret_cast<const f32x4*>(kt + ka_.b[(s + 2) & 3] + 256 * ((s + 2) >> 2));
 #endif
-        if (s == 0) {
-            mfma_v_first(c.a0, ka.x, f.q[s].x);
-            mfma_v_first(c.a1, ka.y, f.q[s].y);
-            mfma_v_first(c.a2, ka.z, f.q[s].z);
-            mfma_v_first(c.a3, ka.w, f.q[s].w);
-        } else {
-            mfma_v(c.a0, ka.x, f.q[s].x);
-            mfma_v(c.a1, ka.y, f.q[s].y);
-            mfma_v(c.a2, ka.z, f.q[s].z);
-            mfma_v(c.a3, ka.w, f.q[s].w);
-        }
+        if (s == 0) mfma_v_first(c.a0, ka.x, f.q[s].x);
+        else mfma_v(c.a0, ka.x, f.q[s].x);
+        mfma_v(c.a0, ka.y, f.q[s].y);
+        mfma_v(c.a0, ka.z, f.q[s].z);
+        mfma_v(c.a0, ka.w, f.q[s].w);
         hook(s);
     }
     if (GEO) mfma_v_first(c.g, xa, f.xq);
@@ -656,7 +643,7 @@ __global__ __launch_bounds__(WAVES * 64) void topk_stream_kernel(TopkStreamArgs 
         QKAcc c;
         const char* kt = my + slot * KT_BYTES;
 #ifdef RANGE_EXP_TS_NOMFMA
-        c.a0 = c.a1 = c.a2 = c.a3 = *reinterpret_cast<const f32x4*>(kt + lane * 16);
+        c.a0 = *reinterpret_cast<const f32x4*>(kt + lane * 16);
 #else
         qk_mfma<false>(kt, qk_first_reads<false>(kt, kt, kaddr), kaddr, f, c,
                        [](int) __attribute__((always_inline)) {});
@@ -1224,10 +1211,8 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
                         // runs >= 20 MFMAs after the last QK MFMA, whose results are long readable
                         const int k = (h - 21) >> 2, r = k / 5, part = k % 5;
                         if (part == 0) {
-                            e1[r] = add1(c.a0[r], c.a1[r]);
-                            e2[r] = add1(c.a2[r], c.a3[r]);
                         } else if (part == 1) {
-                            e1[r] = fmaf(add1(e1[r], e2[r]), a.k_sem, -m1);
+                            e1[r] = fmaf(c.a0[r], a.k_sem, -m1);
                             if (GEO) e2[r] = fmaf(c.g[r], a.k_geo, -m2);
                         } else if (part == 2) {
                             e1[r] = __builtin_amdgcn_exp2f(e1[r]);

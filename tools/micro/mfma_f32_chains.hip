@@ -54,7 +54,7 @@ int main() {
     hipGetDeviceProperties(&p, 0);
     const int n = p.multiProcessorCount;
     run<4, false>(1, n); run<4, true>(1, n); run<8, false>(1, n); run<16, false>(1, n);
-    run<2, false>(1, n);
+    run<2, false>(1, n); run<1, false>(1, n); run<1, false>(4, n);
     run<4, false>(4, n); run<4, true>(4, n); run<2, false>(4, n); run<16, false>(4, n);
     return 0;
 }
