@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded (torch.distributed) path even with one rank "
                          "(rehearsal of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--layout", default="row-sharded", choices=["row-sharded", "query-sharded"],
+                    help="N>1: row-sharded bank with the RCCL exchange (north-star layout, default) or "
+                         "the control: the whole bank on every GPU, each rank embeds its own queries, "
+                         "no collective on the data path")
     ap.add_argument("--shard-chunks", type=int, default=0,
                     help="query chunks of the sharded forward (0 = library default: 4 when N>1)")
     ap.add_argument("--cpu-sample", type=int, default=6144,
@@ -102,8 +106,9 @@ def main():
     dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
-    sharded = world > 1 or a.force_sharded
-    if sharded:
+    replicated = world > 1 and a.layout == "query-sharded"
+    sharded = (world > 1 and not replicated) or a.force_sharded
+    if world > 1 or sharded:
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, shard_rows
         init_from_env(backend)
@@ -137,7 +142,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if sharded:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -150,7 +155,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if sharded:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -163,7 +168,8 @@ def main():
 
     if rank == 0:
         launches_per_step = att_n // a.steps
-        q_per_launch = B * world // launches_per_step  # every rank attends all queries (in chunks)
+        # row-sharded: every rank attends all queries (in chunks); replicated bank: only its own
+        q_per_launch = B * (world if sharded else 1) // launches_per_step
         att_avg_ms = att_ms / att_n
         # which pass 2 ran: on the logits kept by pass 1 (the default) or recomputing them
         kept = eng.kept_queries() > 0
@@ -198,7 +204,9 @@ def main():
                                    f"weights), {a.bank} (synthetic, N={N}), {B} queries per GPU "
                                    "per step, device-resident in/out",
                        "bank_rows": N, "queries_per_gpu": B, "hidden": H,
-                       "bank_layout": "single GPU" if not sharded else f"row-sharded x{world}",
+                       "bank_layout": ("single GPU" if world == 1 and not sharded else
+                                       f"row-sharded x{world}" if sharded else
+                                       f"replicated x{world} (query-sharded control)"),
                        "query_tiles": qt, "bank_splits": ns},
             "roofline": {"kernel": ("attend_stored_kernel<GEO> (pass 2 on kept logits: w@V, f32 MFMA)"
                                     if kept else
@@ -216,7 +224,7 @@ def main():
         if world == 1 and a.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
         print(json.dumps(res))
-    if sharded:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
