@@ -95,3 +95,11 @@ def load_any(path: str, rows: Optional[Tuple[int, int]] = None) -> PreparedBank:
         return load_bankfile(path, rows)
     bank = _load_npz(path)
     return bank if rows is None else bank.rows(*rows)
+
+
+if __name__ == "__main__":      # python -m range_amd.bankfile range_db_large.npz range_db_large.rbank
+    import sys
+
+    if len(sys.argv) != 3:
+        raise SystemExit("usage: python -m range_amd.bankfile <range_db_*.npz> <out.rbank>")
+    print(convert_npz(sys.argv[1], sys.argv[2]))
