@@ -1,42 +1,48 @@
 #!/usr/bin/env python3
 """Headline benchmark: geo-embeddings/sec of the RANGE+ forward path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
 
 One "step" = one pass of the hot path (encode -> stats -> attend -> finalize, i.e.
 ``load_model('RANGE+', beta=0.5)(locs)`` up to the device-resident (B,1280) float64 result) over
-one batch of 10 000 synthetic queries per GPU, against the synthetic ``range_db_large`` bank
-(N = 100 000 rows, SatCLIP-L40 encoder with H = 512; shapes are assumptions).
-Inputs are resident in HBM when the timed region starts; the final device->host copy of the
-reference's numpy contract is NOT in the timed region (PCIe-inclusive rate: DESIGN.md).
+one batch of synthetic queries against the synthetic ``range_db_large`` bank (N = 100 000 rows,
+SatCLIP-L40 encoder with H = 512; shapes are assumptions).  Inputs are resident in
+HBM when the timed region starts; the device->host copy of the reference's numpy contract is NOT
+in the timed region (it is measured separately and reported as ``value_host_contract``).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the bank is row-sharded,
-each rank serves its own 10 000 queries against all shards (range_amd/dist.py) - per-GPU work is
-constant, so the reported scaling is weak.
+N > 1: one rank per GPU over RCCL, the bank row-sharded (range_amd/dist.py).  ``--gpus N`` without
+WORLD_SIZE in the environment starts the N rank processes itself (fresh children of this process,
+which has not touched a GPU) through ``torch.distributed.run`` and relays rank 0's JSON line;
+launched by ``torch.distributed.run`` it is one of the ranks.
+
+  --scaling strong (default) : BASELINE.json's metric - ONE batch of 10 000 queries in total,
+                               10 000 / N per rank; for N > 1 a second, untimed-in-``value``
+                               measurement of the weak mode follows and is reported under "weak"
+  --scaling weak             : 10 000 queries per rank (per-GPU work constant)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from range_amd import _native, synth          # noqa: E402
-from range_amd.bank import prepare_bank       # noqa: E402
+BANKS = ("range_db_large", "range_db_med")
 
 FLOP_PAIR_ATTEND = 2 * (256 + 3 + 1024)       # pass 2 recomputing the logits, per (query, bank row)
 FLOP_PAIR_ATTEND_KEPT = 2 * (3 + 1024)        # pass 2 on the logits pass 1 kept: geo tile + w @ V
 FLOP_PAIR_STATS = 2 * (256 + 3)               # pass 1
 FLOP_PAIR_REFERENCE = 4614                    # the reference's arithmetic
 BANK_ROW_BYTES = (256 + 1024 + 3) * 4         # 5132 B
+KEY_ROW_BYTES = 256 * 4                       # keys-only scan (top-k side channel)
 PEAK_F32_MATRIX_TFLOPS = 157.3                # MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_F64_MATRIX_TFLOPS = 78.6                 # dense f64 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
@@ -45,8 +51,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--queries", type=int, default=10_000, help="queries per GPU per step")
-    ap.add_argument("--bank", default="range_db_large", choices=sorted(synth.BANK_ROWS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = --queries in total (BASELINE's 10k-query batch), "
+                         "weak = --queries per GPU")
+    ap.add_argument("--queries", type=int, default=10_000,
+                    help="queries per step: in total (strong) or per GPU (weak)")
+    ap.add_argument("--bank", default="range_db_large", choices=BANKS)
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--beta", type=float, default=0.5)
     ap.add_argument("--force-sharded", action="store_true",
@@ -57,13 +67,48 @@ def parse():
                          "the control: the whole bank on every GPU, each rank embeds its own queries, "
                          "no collective on the data path")
     ap.add_argument("--shard-chunks", type=int, default=0,
-                    help="query chunks of the sharded forward (0 = library default: 4 when N>1)")
-    ap.add_argument("--cpu-sample", type=int, default=6144,
+                    help="query chunks of the sharded forward (0 = library default)")
+    ap.add_argument("--cpu-sample", type=int, default=4096,
                     help="queries of the same workload timed on the host for cpu_baseline (0=off)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (scan roofline, host-contract rate, weak-mode leg)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# parent: start the ranks (never touches a GPU)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(a) -> int:
+    """``python bench.py --gpus N`` from a plain shell: run N fresh rank processes under
+    torch.distributed.run, pass their output through, return the launcher's exit code (non-zero
+    when any rank failed: the elastic agent tears the others down)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    got_line = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        got_line = got_line or line.lstrip().startswith('{"metric"')
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("bench.py: ranks exited 0 without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# rank process
+# ------------------------------------------------------------------------------------------------
 def encoder_params(L, H):
+    from range_amd import synth
     from range_amd.ckpt import EncoderParams
     w = synth.make_encoder_weights(L, H, 256, 2, 1234)
     return w, EncoderParams(L, H, 2, 256, "analytic",
@@ -71,39 +116,112 @@ def encoder_params(L, H):
                             [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     """The oracle (CPU restatement of the reference, torch CPU ops in the reference's order and
-    dtypes) timed on this box's host cores on a bounded sample of the same workload."""
+    dtypes) timed on this box's host cores on a bounded sample of the same workload: all threads
+    with the SH / Siren / retrieval split of SURVEY.md 8(d), and one thread on a smaller sample."""
+    import numpy as np
+    import torch
     from oracle import range_oracle as O     # checker / baseline only
+    from range_amd import synth
     locs, vals, keys = bank_arrays
     obank = O.prep_bank(locs, vals, keys)
     q = synth.make_queries(n_sample, seed=7)
-    O.forward(q[:64], weights, L, obank, model, beta)          # warm-up
-    t0 = time.perf_counter()
-    O.forward(q, weights, L, obank, model, beta, chunk=512)
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "geo-embeddings/sec", "cores": torch.get_num_threads(),
+
+    def run(qs, chunk):
+        t_sh = t_si = t_re = 0.0
+        for i in range(0, qs.shape[0], chunk):
+            ll = qs[i:i + chunk]
+            t0 = time.perf_counter()
+            y = O.sh_features(ll, L, "analytic")
+            t1 = time.perf_counter()
+            e = torch.from_numpy(O.siren_forward(y, weights))
+            e = (e / e.norm(p=2, dim=-1, keepdim=True)).numpy()
+            t2 = time.perf_counter()
+            O.retrieve(e, ll, obank, model, beta)
+            t3 = time.perf_counter()
+            t_sh += t1 - t0
+            t_si += t2 - t1
+            t_re += t3 - t2
+        return t_sh, t_si, t_re
+
+    n_all = torch.get_num_threads()
+    run(q[:64], 64)                                            # warm-up
+    sh, si, re_ = run(q, 512)
+    dt = sh + si + re_
+    n1 = max(32, min(192, n_sample // 16))
+    torch.set_num_threads(1)
+    try:
+        sh1, si1, re1 = run(q[:n1], n1)
+    finally:
+        torch.set_num_threads(n_all)
+    dt1 = sh1 + si1 + re1
+    return {"value": n_sample / dt, "unit": "geo-embeddings/sec", "cores": n_all,
             "kind": "port",
             "sample": f"{n_sample} of the 10000-query batch, same bank, chunks of 512, "
-                      f"{dt:.1f} s, host has {os.cpu_count()} logical CPUs"}
+                      f"{dt:.1f} s; host: {cpu_model_name()}, {os.cpu_count()} logical CPUs",
+            "split_s": {"sh_features": sh, "siren": si, "retrieval": re_},
+            "split_q_per_s": {"sh_features": n_sample / sh, "siren": n_sample / si,
+                              "retrieval": n_sample / re_},
+            "one_thread": {"value": n1 / dt1, "cores": 1, "sample": f"{n1} queries, {dt1:.1f} s",
+                           "split_s": {"sh_features": sh1, "siren": si1, "retrieval": re1}}}
+
+
+def pmc_traffic(kernel, B, N, qt, ns):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/attend_pmc.json: a list of entries keyed by kernel and launch geometry).  A static
+    figure from an earlier profiled run of the SAME workload - None when no entry matches."""
+    path = os.path.join(REPO, "profiles", "attend_pmc.json")
+    try:
+        entries = json.load(open(path))
+    except Exception:
+        return None, "no profiles/attend_pmc.json"
+    if isinstance(entries, dict):
+        entries = [entries]
+    for e in entries:
+        if (e.get("kernel_key") == kernel and e.get("queries") == B and e.get("bank_rows") == N
+                and e.get("query_tiles") == qt and e.get("bank_splits") == ns):
+            return e.get("hbm_bytes_per_launch"), \
+                f"profiles/attend_pmc.json (static: rocprofv3 --pmc passes of {e.get('source', '?')})"
+    return None, "no PMC entry for this workload/geometry in profiles/attend_pmc.json"
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
+    import numpy as np
+    import torch
+
+    from range_amd import _native, synth
+    from range_amd.bank import prepare_bank
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     # RANGE_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
     # (ranks share devices, collectives are staged through the host; the timing means nothing)
     backend = os.environ.get("RANGE_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, {n_dev} visible "
+                         "(RANGE_DIST_BACKEND=gloo rehearses the path on fewer)")
+    dev = torch.device("cuda", local if backend == "nccl" else local % n_dev)
     torch.cuda.set_device(dev)
     dist = None
     replicated = world > 1 and a.layout == "query-sharded"
@@ -120,6 +238,7 @@ def main():
     bank = prepare_bank(*bank_arrays)
     eng = _native.HipEngine(dev)
     eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
+    model = None
     if not sharded:
         eng.set_bank(bank.keys, bank.values, bank.xyz, 0)
         n_local = N
@@ -130,49 +249,102 @@ def main():
         n_local = r1 - r0
         model = ShardedRange(eng, "RANGE+", a.beta, n_chunks=a.shard_chunks or None)
 
-    B = a.queries
-    x = torch.from_numpy(synth.make_queries(B, seed=7 + rank)).to(dev)
-    out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
-
-    def step():
-        if not sharded:
-            eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
-        else:
-            out.copy_(model(x))
-
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    eng.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    att_ms, att_n = eng.profile_read(_native.PROF_ATTEND)
-    st_ms, st_n = eng.profile_read(_native.PROF_SCAN_STATS)
-    en_ms, en_n = eng.profile_read(_native.PROF_ENCODER)
-    eng.profile_enable(False)
-    assert att_n >= a.steps and att_n % a.steps == 0, (att_n, a.steps)   # sharded: one per chunk
-    assert bool(torch.isfinite(out).all())
+    def measure(scaling, steps, warmup):
+        """One timed leg.  Returns a dict of raw measurements (rank-local except dt = max over ranks)."""
+        if scaling == "strong":
+            if a.queries % world:
+                raise SystemExit(f"--queries {a.queries} is not a multiple of --gpus {world}")
+            B = a.queries // world
+        else:
+            B = a.queries
+        # the batch of the step: rank r owns queries [r*B, (r+1)*B) of ONE seeded batch
+        q_all = synth.make_queries(B * world, seed=7)
+        q_host = q_all[rank * B:(rank + 1) * B]
+        x = torch.from_numpy(q_host).to(dev)
+        out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+
+        def step():
+            if not sharded:
+                eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+            else:
+                out.copy_(model(x))
+
+        for _ in range(warmup):
+            step()
+        eng.profile_enable(True)
+        if model is not None:
+            model.comm_timing(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prof = {k: eng.profile_read(v) for k, v in (("attend", _native.PROF_ATTEND),
+                                                    ("scan_stats", _native.PROF_SCAN_STATS),
+                                                    ("encoder", _native.PROF_ENCODER))}
+        eng.profile_enable(False)
+        comm_ms = model.comm_timing(False) if model is not None else None
+        assert prof["attend"][1] >= steps and prof["attend"][1] % steps == 0, (prof, steps)
+        assert bool(torch.isfinite(out).all())
+        return {"B": B, "dt": dt, "prof": prof, "comm_ms": comm_ms, "q_host": q_host, "out": out,
+                "kept": eng.kept_queries() > 0, "geometry": eng.last_geometry()}
+
+    m = measure(a.scaling, a.steps, a.warmup)
+    B, dt = m["B"], m["dt"]
+
+    # ---- parity of the timed result (outside the timed region): 64 of rank 0's rows against the
+    #      oracle in the reference's float32 op order and in exact float64
+    parity = None
+    if rank == 0:
+        from oracle import range_oracle as O     # checker only
+        obank = O.prep_bank(*bank_arrays)
+        idx = np.linspace(0, B - 1, num=min(64, B), dtype=np.int64)
+        qs = m["q_host"][idx]
+        got = m["out"][torch.from_numpy(idx).to(dev)].cpu().numpy()
+        e = O.encode(qs, weights, L)
+        ref32 = O.retrieve(e, qs, obank, "RANGE+", a.beta)
+        ref64 = O.retrieve64(e, qs, obank, "RANGE+", a.beta)
+        parity = {"rows": int(idx.size),
+                  "max_abs_vs_reference_f32_order": float(np.abs(got - ref32).max()),
+                  "max_abs_vs_f64_oracle": float(np.abs(got[:, :1024] - ref64).max()),
+                  "ehat_max_abs": float(np.abs(got[:, 1024:] - e).max())}
+        if not parity["max_abs_vs_reference_f32_order"] < 1e-4:
+            raise SystemExit(f"bench parity failed: {parity}")
+
+    # ---- untimed extras
+    weak = None
+    if world > 1 and a.scaling == "strong" and not a.no_extras:
+        mw = measure("weak", a.steps, max(1, a.warmup))
+        weak = {"value": mw["B"] * world * a.steps / mw["dt"], "ms_per_step": mw["dt"] / a.steps * 1e3,
+                "queries_per_gpu": mw["B"], "comm_ms_exposed_per_step":
+                    None if mw["comm_ms"] is None else mw["comm_ms"] / a.steps}
+    scan = None
+    host_contract = None
+    if world == 1 and not sharded and not a.no_extras:
+        scan = scan_roofline(eng, synth, torch, dev, N)
+        host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
 
     if rank == 0:
+        att_ms, att_n = m["prof"]["attend"]
+        st_ms, st_n = m["prof"]["scan_stats"]
+        en_ms, en_n = m["prof"]["encoder"]
         launches_per_step = att_n // a.steps
         # row-sharded: every rank attends all queries (in chunks); replicated bank: only its own
-        q_per_launch = B * (world if sharded else 1) // launches_per_step
+        q_scanned = B * (world if sharded else 1)
+        q_per_launch = q_scanned // launches_per_step
         att_avg_ms = att_ms / att_n
-        # which pass 2 ran: on the logits kept by pass 1 (the default) or recomputing them
-        kept = eng.kept_queries() > 0
+        kept = m["kept"]     # which pass 2 ran: on the logits pass 1 kept (default) or recomputing
         flops = q_per_launch * n_local * (FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND)
         achieved = flops / (att_avg_ms * 1e-3) / 1e12
         # algorithmic bytes of one launch: the bank columns it reads once, per-query operands and
@@ -181,52 +353,127 @@ def main():
             alg_bytes = n_local * (1024 + 4) * 4 + q_per_launch * (32 + 4096) + q_per_launch * n_local * 4
         else:
             alg_bytes = n_local * BANK_ROW_BYTES + q_per_launch * (1040 + 4096)
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "attend_pmc.json")
-        if not sharded and os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                if ("stored" in j.get("kernel", "")) == kept:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        qt, ns = eng.last_geometry()
+        qt, ns = m["geometry"]
+        kernel_key = "attend_stored_kernel<true>" if kept else "attend_kernel<true>"
+        traffic, traffic_source = (pmc_traffic(kernel_key, q_per_launch, n_local, qt, ns)
+                                   if not sharded else (None, "not profiled for the sharded layout"))
+        step_s = dt / a.steps
+        st_flops = q_scanned * n_local * FLOP_PAIR_STATS
+        en_flops = B * 2 * (L * L * H + H * H + 256 * H)
+        executed = (q_scanned * n_local * ((FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND)
+                                           + FLOP_PAIR_STATS) + en_flops)
         total_q = B * world * a.steps
+        per_gpu = "in total" if a.scaling == "strong" else "per GPU"
         res = {
             "metric": "geo-embeddings/sec (10k-query batch, range_db_large)",
             "value": total_q / dt,
             "unit": "geo-embeddings/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_s * 1e3,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"RANGE+ beta={a.beta}, SatCLIP-L40 encoder (H={H}, synthetic "
-                                   f"weights), {a.bank} (synthetic, N={N}), {B} queries per GPU "
-                                   "per step, device-resident in/out",
-                       "bank_rows": N, "queries_per_gpu": B, "hidden": H,
+                                   f"weights), {a.bank} (synthetic, N={N}), {a.queries} queries "
+                                   f"{per_gpu} per step ({B} per GPU), device-resident in/out",
+                       "bank_rows": N, "queries_total": B * world, "queries_per_gpu": B, "hidden": H,
                        "bank_layout": ("single GPU" if world == 1 and not sharded else
                                        f"row-sharded x{world}" if sharded else
                                        f"replicated x{world} (query-sharded control)"),
-                       "query_tiles": qt, "bank_splits": ns},
+                       "bank_rows_per_gpu": n_local, "query_tiles": qt, "bank_splits": ns},
             "roofline": {"kernel": ("attend_stored_kernel<GEO> (pass 2 on kept logits: w@V, f32 MFMA)"
                                     if kept else
                                     "attend_kernel<GEO> (pass 2: logits + w@V, f32 MFMA)"),
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": att_avg_ms, "launches": att_n,
+                         "queries_per_launch": q_per_launch,
                          "flop_per_launch": flops,
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "kernels_ms_per_step": {"encoder": en_ms / a.steps, "scan_stats": st_ms / a.steps,
-                                    "attend": att_ms / a.steps},
-            "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / (dt / a.steps) / 1e12,
+            # every kernel of the step against the peak that bounds it (HIP events on the launch
+            # stream, averaged over the timed steps)
+            "kernels": {
+                "encoder": {"ms_per_step": en_ms / a.steps, "bound": "mfma f64",
+                            "achieved_tflops": en_flops / (en_ms / a.steps * 1e-3) / 1e12,
+                            "frac": en_flops / (en_ms / a.steps * 1e-3) / 1e12 / PEAK_F64_MATRIX_TFLOPS},
+                "scan_stats": {"ms_per_step": st_ms / a.steps, "bound": "mfma f32",
+                               "achieved_tflops": st_flops / (st_ms / a.steps * 1e-3) / 1e12,
+                               "frac": st_flops / (st_ms / a.steps * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS},
+                "attend": {"ms_per_step": att_ms / a.steps, "bound": "mfma f32",
+                           "achieved_tflops": achieved, "frac": achieved / PEAK_F32_MATRIX_TFLOPS},
+                "other_ms_per_step": step_s * 1e3 - (en_ms + st_ms + att_ms) / a.steps},
+            "executed_tflops": executed / step_s / 1e12,
+            "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / step_s / 1e12,
+            "parity_max_abs": parity["max_abs_vs_reference_f32_order"],
+            "parity": parity,
         }
+        if dist is not None:
+            res["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "layout": a.layout if world > 1 else "row-sharded (forced, one rank)",
+                           "comm_ms_exposed_per_step":
+                               None if m["comm_ms"] is None else m["comm_ms"] / a.steps}
+        if weak is not None:
+            res["weak"] = weak
+        if scan is not None:
+            res["roofline_scan"] = scan
+        if host_contract is not None:
+            res["value_host_contract"] = host_contract["value"]
+            res["host_contract"] = host_contract
         if world == 1 and a.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scan_roofline(eng, synth, torch, dev, N):
+    """The HBM-bound regime of the path: the keys-only top-k scan (``range_topk_stream``) for a
+    handful of queries.  One pass streams the N x 1 KB key rows once per 16 queries; achieved =
+    passes x N x 1024 B / the kernel's mean launch time (HIP events on the launch stream)."""
+    from range_amd import _native
+    out = []
+    for nq in (16, 64):
+        x = torch.from_numpy(synth.make_queries(nq, seed=11)).to(dev)
+        _, e32, _ = eng.encode(x)
+        for _ in range(5):
+            eng.topk_stream(e32, 16)
+        eng.profile_enable(True)
+        reps = 30
+        for _ in range(reps):
+            eng.topk_stream(e32, 16)
+        torch.cuda.synchronize(dev)
+        ms, n = eng.profile_read(_native.PROF_TOPK_STREAM)
+        eng.profile_enable(False)
+        passes = (nq + 15) // 16
+        byts = passes * N * KEY_ROW_BYTES
+        us = ms / n * 1e3
+        out.append({"kernel": "topk_stream_kernel", "queries": nq, "passes": passes, "bytes": byts,
+                    "avg_us": us, "launches": n, "achieved_TBps": byts / (us * 1e-6) / 1e12,
+                    "peak_TBps": PEAK_HBM_GBS / 1e3, "frac": byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS})
+    return out
+
+
+def host_contract_rate(eng, synth, torch, dev, beta, B):
+    """The reference's own contract: ``model(x)`` returns a FRESH host ndarray (B,1280) float64
+    (range/range.py:240).  Timed as the caller's loop of synchronous calls; never ``value``."""
+    from range_amd import _native
+    if not hasattr(eng, "forward_host"):
+        return None
+    xs = [torch.from_numpy(synth.make_queries(B, seed=100 + i)).to(dev) for i in range(4)]
+    eng.forward_host(xs[0], _native.MODEL_RANGE_PLUS, beta)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 0
+    keep = []
+    for rep in range(2):
+        for x in xs:
+            keep.append(eng.forward_host(x, _native.MODEL_RANGE_PLUS, beta))   # results stay alive
+            n += x.shape[0]
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "geo-embeddings/sec", "ms_per_batch": dt / (2 * len(xs)) * 1e3,
+            "what": f"{2 * len(xs)} synchronous calls of {B} queries, each returning a fresh "
+                    "host ndarray (B,1280) float64; inputs resident in HBM"}
 
 
 if __name__ == "__main__":

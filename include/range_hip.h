@@ -21,17 +21,19 @@
 #ifndef RANGE_HIP_H
 #define RANGE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 2
+#define RANGE_ABI_VERSION 3
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
 #define RANGE_OUT_DIM 1280  /* location_feature_dim,     range/range.py:86     */
+#define RANGE_MAX_TAU 43.0f /* largest temperature (the reference's: 12, 15, 40; range.py:103-109) */
 
 enum {
     RANGE_OK = 0,
@@ -59,6 +61,10 @@ typedef struct range_encoder_desc {
 
 int range_abi_version(void);
 const char* range_last_error(void);
+/* The extra compiler flags this library was built with (build.sh records them); "" for the
+ * default build.  A build carrying RANGE_EXP_* switches is a timing experiment whose results are
+ * invalid: the Python binding refuses to load it. */
+const char* range_build_flags(void);
 
 /* Create / destroy an engine context on GPU `device`. */
 int range_create(int device, range_ctx** out);
@@ -112,9 +118,15 @@ int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev,
 /* Kernel B, pass 1.  Streaming log-sum-exp statistics of the temperature-scaled logits of
  * range/range.py:213-215 (semantic) and :231-234 (geographic) over THIS ctx's bank rows.
  *   tau_sem, tau_geo : temperatures (range.py:103, 108-109); tau_geo <= 0 disables the geo head
- *   stats_dev : (B,4) float32 = {m_sem, l_sem, m_geo, l_geo}, m = max of tau*log2(e)*logit,
- *               l = sum 2^(t - m) over the rows.  Opaque to callers except through
- *               range_merge_stats.
+ *   ehat32_dev / xq32_dev rows must be UNIT vectors (what range_encode emits; range.py:212,
+ *               utils.py:11-16) and the bank keys / xyz are (range.py:85-89, :93-95): every logit
+ *               is then <= 1 and the statistics use the constant shift m = tau*log2(e) instead of
+ *               a running maximum (no rescaling; partial statistics merge by plain sums).
+ *               Temperatures above RANGE_MAX_TAU are rejected (2^(-2m) must stay a normal float).
+ *   stats_dev : (B,4) float32 = {m_sem, l_sem, m_geo, l_geo}, m = tau*log2(e),
+ *               l = sum 2^(tau*log2(e)*logit - m) over the rows; log-sum-exp = (m + log2 l)/log2 e.
+ *               Statistics of disjoint row sets (bank splits, bank shards) of the same query
+ *               have the same m and their l add: range_merge_stats, or an all-reduce(sum).
  *   topk : 0, or k in [1,16]: also emit the k largest semantic similarities of each query
  *          (the "brute-force top-k" side channel), descending, ties -> lower row index:
  *          topk_val_dev (B,k) float32, topk_idx_dev (B,k) int64 (global row = row_offset + local).
@@ -137,11 +149,17 @@ int64_t range_kept_queries(const range_ctx* ctx);
 
 /* Small-batch top-k, the HBM-streaming form of the keys scan (no reference counterpart; north star:
  * "brute-force cosine-similarity top-k ... coalesced HBM-streaming kernel with per-wavefront
- * running top-k").  Every wave streams its own 16-row key tiles against groups of 16 queries;
- * meant for B up to a few dozen (each group of 16 queries re-streams the keys).  Same outputs and
- * tie rule as the top-k of range_scan_stats. */
+ * running top-k").  A persistent grid (one workgroup per CU): every wave streams its own 16-row
+ * key tiles through a wave-private LDS ring against groups of 16 queries in registers; 1, 2 or 4
+ * groups share one pass over the keys (<= 32 queries per pass is the HBM-bound regime), further
+ * groups take further passes inside the same launch.  Meant for B up to about a hundred.  Same
+ * outputs and tie rule as the top-k of range_scan_stats.  Per-lane candidate lists are short
+ * (8 entries); a query whose lists may have dropped a top-k member (detected exactly) is
+ * recomputed by brute force inside the merge kernel - range_topk_stream_exact_count reports how
+ * many queries took that path since the context was created (synchronises the device). */
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
+int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);
 
 /* Exact merge of per-shard statistics (row-sharded bank): parts_dev is (n_parts,B,4) as written
  * by range_scan_stats on each shard (e.g. after an all-gather); out_dev is (B,4). */
@@ -192,6 +210,21 @@ int range_finalize(range_ctx* ctx, const float* partials_dev, int32_t n_parts,
 int range_forward(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t model, float beta,
                   double* out_dev, range_stream_t stream);
 
+/* The same path with the reference's own output contract: the result lands in HOST memory
+ * (range/range.py:240 returns a numpy array; range/utils/save.py:27-30 consumes it).  out_host is
+ * the caller's (B,1280) float64 array, pageable and typically fresh (untouched pages).  The call
+ * returns when out_host is complete (it is synchronous, like the reference's `.cpu()`): finalize
+ * runs per slab of 1024 queries, each slab's device->host DMA (pinned staging, a copy stream of
+ * the context) overlaps the next slab's, and a few host threads (RANGE_HOST_THREADS, default
+ * min(16, cores)) move landed slabs into out_host so that its first-touch page faults are spread
+ * over cores. */
+int range_forward_host(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t model,
+                       float beta, double* out_host, range_stream_t stream);
+
+/* dst[0,bytes) = src[0,bytes) on the host with the context's copy threads (used by the batch
+ * driver to fill fresh result arrays from pinned staging memory). */
+int range_host_copy(range_ctx* ctx, void* dst, const void* src, size_t bytes);
+
 /* Introspection for the bench harness: launch geometry of the last scan/attend launch. */
 int range_last_attend_geometry(const range_ctx* ctx, int32_t* n_query_tiles, int32_t* n_splits);
 
@@ -200,7 +233,8 @@ int range_last_attend_geometry(const range_ctx* ctx, int32_t* n_query_tiles, int
  * range/evaluation/visualize_embeddings.py:101-116).  range_profile_enable(ctx,1) starts
  * collecting (and clears earlier samples); range_profile_read synchronises with the recorded
  * events and returns the summed duration and the number of launches of one kernel. */
-enum { RANGE_PROF_ENCODER = 0, RANGE_PROF_SCAN_STATS = 1, RANGE_PROF_ATTEND = 2 };
+enum { RANGE_PROF_ENCODER = 0, RANGE_PROF_SCAN_STATS = 1, RANGE_PROF_ATTEND = 2,
+       RANGE_PROF_TOPK_STREAM = 3, RANGE_PROF_KINDS = 4 };
 int range_profile_enable(range_ctx* ctx, int32_t on);
 int range_profile_read(range_ctx* ctx, int32_t which, double* total_ms, int32_t* launches);
 

@@ -14,24 +14,27 @@ import numpy as np
 import torch
 
 LIB_NAME = "librange_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# RANGE_LIB_PATH: load another build of the library (tuning sweeps; see tools/topk_stream_sweep.sh)
+LIB_PATH = os.environ.get("RANGE_LIB_PATH") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 KEY_DIM, VAL_DIM, OUT_DIM = 256, 1024, 1280
 SH_ANALYTIC, SH_CLOSED_FORM = 0, 1
 MODEL_RANGE, MODEL_RANGE_PLUS = 0, 1
 MAX_TOPK = 16
-PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND = 0, 1, 2   # range_profile_read(which)
+PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND, PROF_TOPK_STREAM = 0, 1, 2, 3   # range_profile_read(which)
 COORD_DIRECT, COORD_CARTESIAN3D, COORD_WRAP = 0, 1, 2   # range_coord_features(mode)
 COORD_DIMS = {COORD_DIRECT: 2, COORD_CARTESIAN3D: 3, COORD_WRAP: 4}
 
 # every symbol include/range_hip.h declares
 SYMBOLS = (
-    "range_abi_version", "range_last_error", "range_create", "range_destroy", "range_set_encoder",
+    "range_abi_version", "range_last_error", "range_build_flags", "range_create", "range_destroy", "range_set_encoder",
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
-    "range_coord_features", "range_attend_kept", "range_kept_queries",
+    "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
+    "range_host_copy", "range_topk_stream_exact_count",
 )
 
 
@@ -61,6 +64,7 @@ def load_library() -> C.CDLL:
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.range_abi_version.restype = C.c_int
     lib.range_last_error.restype = C.c_char_p
+    lib.range_build_flags.restype = C.c_char_p
     lib.range_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.range_destroy.argtypes = [vp]
     lib.range_destroy.restype = None
@@ -78,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.range_attend.argtypes = [vp, vp, vp, i64, f32, f32, f32, vp, vp, vp]
     lib.range_finalize.argtypes = [vp, vp, i32, vp, i64, vp, vp]
     lib.range_forward.argtypes = [vp, vp, i64, i32, f32, vp, vp]
+    lib.range_forward_host.argtypes = [vp, vp, i64, i32, f32, vp, vp]
+    lib.range_host_copy.argtypes = [vp, vp, vp, C.c_size_t]
     lib.range_last_attend_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.range_profile_enable.argtypes = [vp, i32]
     lib.range_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i32)]
@@ -85,11 +91,17 @@ def load_library() -> C.CDLL:
     lib.range_encode_raw.argtypes = [vp, vp, i64, vp, vp]
     lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.range_topk_stream_exact_count.argtypes = [vp, C.POINTER(i64)]
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 2:
-        raise RangeNativeError("librange_hip.so ABI version mismatch")
+    if lib.range_abi_version() != 3:
+        raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
+    flags = lib.range_build_flags().decode()
+    if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":
+        raise RangeNativeError(
+            f"{LIB_PATH} was built with timing-experiment switches ({flags}): its results are "
+            "invalid.  Rebuild with ./build.sh (RANGE_ALLOW_EXPERIMENT_BUILD=1 overrides, tuning only).")
     _lib = lib
     return lib
 
@@ -266,6 +278,13 @@ class HipEngine:
                                                     ti.data_ptr(), self._stream()))
         return tv, ti
 
+    def topk_stream_exact_count(self) -> int:
+        """Queries topk_stream recomputed by brute force (its short per-lane lists could have
+        dropped a top-k member) since this engine was created."""
+        n = C.c_int64()
+        _check(self.lib, self.lib.range_topk_stream_exact_count(self._h, C.byref(n)))
+        return n.value
+
     def merge_stats(self, parts: torch.Tensor) -> torch.Tensor:
         if parts.dim() != 3 or parts.shape[2] != 4:
             raise ValueError("parts must be (n_parts,B,4)")
@@ -321,6 +340,30 @@ class HipEngine:
         _check(self.lib, self.lib.range_forward(self._h, lonlat.data_ptr(), B, model, beta,
                                                 out.data_ptr(), self._stream()))
         return out
+
+    def forward_host(self, lonlat: torch.Tensor, model: int, beta: float,
+                     out: Optional[np.ndarray] = None) -> np.ndarray:
+        """The reference's contract (range/range.py:240): the (B,1280) float64 result as a host
+        ndarray - a fresh one unless ``out`` (C-contiguous rows of a float64 array) is given.
+        Synchronous; the device->host copy and the fill of the array are pipelined per slab
+        inside the library (range_forward_host)."""
+        self._t(lonlat, torch.float64, (2,))
+        B = lonlat.shape[0]
+        if out is None:
+            out = np.empty((B, OUT_DIM), dtype=np.float64)
+        elif out.shape != (B, OUT_DIM) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array (B,1280)")
+        _check(self.lib, self.lib.range_forward_host(self._h, lonlat.data_ptr(), B, model, beta,
+                                                     out.ctypes.data, self._stream()))
+        return out
+
+    def host_copy(self, dst: np.ndarray, src: np.ndarray) -> None:
+        """dst[...] = src on the host with the library's copy threads (both C-contiguous, same
+        size in bytes): spreads the first-touch page faults of a fresh ``dst`` over cores."""
+        if dst.nbytes != src.nbytes or not dst.flags.c_contiguous or not src.flags.c_contiguous:
+            raise ValueError("host_copy needs C-contiguous arrays of equal size")
+        _check(self.lib, self.lib.range_host_copy(self._h, dst.ctypes.data, src.ctypes.data,
+                                                  dst.nbytes))
 
     def profile_enable(self, on: bool = True) -> None:
         _check(self.lib, self.lib.range_profile_enable(self._h, 1 if on else 0))

@@ -374,7 +374,16 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     KAddr kaddr;
     kaddr.init(lane);
 
-    float m1 = NEG_BIG, l1 = 0.f, m2 = NEG_BIG, l2 = 0.f;
+    // Softmax statistics with a CONSTANT shift.  Both logit rows are dot products of unit vectors
+    // (range.py:212 normalises e-hat, :85-89 the keys; utils.py:11-16 gives unit xyz), so
+    // t = k * s <= k: the shift m = k (tau * log2 e: 17.3 / 21.6 / 57.7) replaces the running
+    // maximum of an online softmax.  2^(t - m) then lies in [2^-2k, 1] - at least 2^-116, a normal
+    // float32, for tau <= 43 (checked on the host) - so the statistic of an element is one fma,
+    // one exp2 and one add, there is no rescaling, and the statistics of lanes, splits and bank
+    // shards merge by plain sums.  Floating point keeps the relative precision of the sum whatever
+    // the shift.
+    float l1 = 0.f, l2 = 0.f;
+    const float nm1 = -a.k_sem, nm2 = -a.k_geo;
     float smax = -INFINITY;      // largest similarity of this lane's rows (a.rowmax)
     TopK<TOPK ? MAX_TOPK : 1> tk;
     if (TOPK) tk.init();
@@ -404,44 +413,33 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
         if (a.logits)   // keep the tile for pass 2 (the barrier's vmcnt(0) also covers this store)
             *reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
         // statistics of this tile.  Only the bank's last block can hold pad rows: every other
-        // tile takes the unmasked form (a quarter fewer VALU instructions; pass 1 issues more of
-        // those than MFMAs, and they are not entirely hidden behind the other waves' MFMAs)
+        // tile takes the unmasked form
         const int64_t row0 = (int64_t)(b0 + t) * BLK;
         const int n_here = (int)(a.n_valid - row0 < BLK ? a.n_valid - row0 : BLK);   // valid rows
         auto tile_stats = [&](auto masked_tag) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-            float t1[4], t2[4];
             bool ok[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pr = pi_row(4 * g + r);
                 ok[r] = !MASKED || pr < n_here;
-                t1[r] = ok[r] ? ss[r] * a.k_sem : NEG_BIG;
-                if (GEO) t2[r] = ok[r] ? sg[r] * a.k_geo : NEG_BIG;
                 if (TOPK) { if (ok[r]) tk.push(ss[r], (int32_t)(row0 + pr)); }
             }
             if (a.rowmax)
                 smax = fmaxf(smax, fmaxf(fmaxf(ok[0] ? ss[0] : -INFINITY, ok[1] ? ss[1] : -INFINITY),
                                          fmaxf(ok[2] ? ss[2] : -INFINITY, ok[3] ? ss[3] : -INFINITY)));
 #ifndef RANGE_EXP_P1_NOVALU
-            {
-                const float mx = fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3]));
-                const float mn = fmaxf(m1, mx);
-                float acc = l1 * __builtin_amdgcn_exp2f(m1 - mn);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t1[r] - mn) : 0.f;
-                l1 = acc; m1 = mn;
-            }
-            if (GEO) {
-                const float mx = fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3]));
-                const float mn = fmaxf(m2, mx);
-                float acc = l2 * __builtin_amdgcn_exp2f(m2 - mn);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc += ok[r] ? __builtin_amdgcn_exp2f(t2[r] - mn) : 0.f;
-                l2 = acc; m2 = mn;
+            for (int r = 0; r < 4; ++r) {
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(ss[r], a.k_sem, nm1));
+                l1 += ok[r] ? p1 : 0.f;
+                if (GEO) {
+                    const float p2 = __builtin_amdgcn_exp2f(fmaf(sg[r], a.k_geo, nm2));
+                    l2 += ok[r] ? p2 : 0.f;
+                }
             }
 #else
-            l1 += t1[0] + t1[3]; if (GEO) l2 += t2[1];
+            l1 += ss[0] + ss[3]; if (GEO) l2 += sg[1];
 #endif
         };
         if (n_here == BLK) tile_stats(std::false_type{});
@@ -451,9 +449,11 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
     // lanes j, j+16, j+32, j+48 hold disjoint row subsets of the same query
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
-        merge_ml(m1, l1, __shfl_xor(m1, off), __shfl_xor(l1, off));
-        if (GEO) merge_ml(m2, l2, __shfl_xor(m2, off), __shfl_xor(l2, off));
+        l1 += __shfl_xor(l1, off);
+        if (GEO) l2 += __shfl_xor(l2, off);
     }
+    const float m1 = a.k_sem;
+    float m2 = a.k_geo;
     if (!GEO) { m2 = NEG_BIG; l2 = 0.f; }   // "no rows": stays so under any merge
     if (q < a.B) {
         if (a.rowmax) a.rowmax[((int64_t)split * a.B + q) * 4 + g] = smax;   // before the lane merge
@@ -473,16 +473,8 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small-batch top-k: the HBM-streaming form of the keys scan.
-//
-// For a handful of queries the scan is bound by streaming the 104 MB of keys, not by MFMA, and
-// the 64-queries-per-workgroup decomposition above wastes the machine (a 16-query batch keeps one
-// wave in four busy).  Here every WAVE streams its own 16-row key tiles (wave-private LDS ring of
-// two tiles filled by LDS-DMA, no workgroup barrier in the loop) against the SAME group of <= 16
-// queries held in registers, and keeps a running top-K per lane in registers as 64-bit keys
-// (ordered value bits << 32 | ~row): larger key = larger similarity, ties -> lower row index.
-// Lists are merged per query across the 4 lane groups (shuffles), the 4 waves (LDS) and finally
-// the workgroups (merge_lists_kernel).  blockIdx.y = query group (16 queries each).
+// Top-k lists: 64-bit keys (ordered value bits << 32 | ~row): larger key = larger similarity,
+// ties -> lower row index.  (The small-batch HBM-streaming scan that uses them: topk_stream.h.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long topk_key(float v, uint32_t row) {
     const uint32_t b = __float_as_uint(v);
@@ -519,37 +511,6 @@ struct KeyList {                       // sorted descending; 0 = empty slot
     }
 };
 
-// The same list kept as separate 32-bit values and rows while it is being filled: a 32-bit float
-// compare and 4 selects per insertion step instead of a 64-bit compare (quarter rate) and 4
-// selects.  Rows must be pushed in increasing order: the strict '>' then keeps the lower row among
-// equal values, which is the order of the 64-bit keys it is converted to for the merges.
-// (Also tried for the stream kernel: parking 8 tiles' values and one bitonic sort + merge per
-// chunk - 288 compare-exchanges of 64-bit keys per 8 tiles - which was slower than this.)
-struct ValList {
-    float v[MAX_TOPK];
-    uint32_t row[MAX_TOPK];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) { v[i] = -INFINITY; row[i] = 0xFFFFFFFFu; }
-    }
-    __device__ __forceinline__ void push(float x, uint32_t r) {
-        if (x > v[MAX_TOPK - 1]) {
-            v[MAX_TOPK - 1] = x; row[MAX_TOPK - 1] = r;
-#pragma unroll
-            for (int i = MAX_TOPK - 1; i > 0; --i) {
-                const bool up = v[i] > v[i - 1];
-                const float hv = up ? v[i] : v[i - 1], lv = up ? v[i - 1] : v[i];
-                const uint32_t hr = up ? row[i] : row[i - 1], lr = up ? row[i - 1] : row[i];
-                v[i - 1] = hv; v[i] = lv; row[i - 1] = hr; row[i] = lr;
-            }
-        }
-    }
-    __device__ __forceinline__ void to_keys(KeyList& L) const {
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) L.k[i] = row[i] == 0xFFFFFFFFu ? 0ull : topk_key(v[i], row[i]);
-    }
-};
-
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x, int m) {
     const uint32_t lo = __shfl_xor((uint32_t)x, m), hi = __shfl_xor((uint32_t)(x >> 32), m);
     return ((unsigned long long)hi << 32) | lo;
@@ -571,125 +532,6 @@ __device__ __forceinline__ void merge_lane_groups(KeyList& L) {
     L = R;
 }
 
-struct TopkStreamArgs {
-    const float* keys;       // (n_pad,256)
-    const float* ehat;       // (B,256)
-    unsigned long long* cand;   // (n_groups, n_wg, 16 queries, 16) keys
-    int64_t B;
-    int64_t n_valid;
-    int32_t n_blocks;
-};
-
-// WAVES waves per workgroup, each with a private ring of DEPTH key tiles (DEPTH-1 of them in
-// flight while one is consumed); WAVES * DEPTH * 16 KB of LDS.  Measured (tools/
-// topk_stream_sweep.sh): the bare LDS-DMA stream tops out at 5.6 TB/s for any
-// geometry; with the MFMAs and the list maintenance (the costliest part: 1.6 us per tile and
-// wave, every wave sees too few rows for its lists to saturate) 4 waves x 2 slots is fastest.
-// RANGE_EXP_TS_NOPUSH / RANGE_EXP_TS_NOMFMA: timing experiments only (results invalid).
-template <int WAVES, int DEPTH>
-constexpr int topks_lds_bytes() { return WAVES * DEPTH * BLK * KEY_DIM * 4; }
-
-template <int WAVES, int DEPTH>
-__global__ __launch_bounds__(WAVES * 64) void topk_stream_kernel(TopkStreamArgs a) {
-    static_assert(WAVES <= 4 && (DEPTH - 1) * 16 <= 63, "list merge uses 4 lane groups; vmcnt is 6 bits");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * DEPTH * KT_BYTES;
-    const char* my = smem + wave * DEPTH * KT_BYTES;
-
-    const int group = blockIdx.y;
-    const int64_t q = (int64_t)group * 16 + (lane & 15);
-    const int n_waves = gridDim.x * WAVES;
-    const int w_id = blockIdx.x * WAVES + wave;
-    // one tile = 16 rows = 16 DMA instructions (4 groups of 4 rows, swizzled source); past the
-    // end of the bank the last tile is fetched again (never consumed), so that every wait below
-    // is a constant
-    const int last = a.n_blocks - 1;
-    auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
-        const float* src = a.keys + (int64_t)(tile < last ? tile : last) * BLK * KEY_DIM;
-#pragma unroll
-        for (int gr = 0; gr < 4; ++gr) {
-            dma_group_begin(lds0 + slot * KT_BYTES + gr * 4096);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                dma_b128_q(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i)) << 4), i);
-        }
-    };
-    // first keys on their way before anything else: tiles t0, t0+n_waves, ... into slots 0..DEPTH-2
-    int tile = w_id;
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) issue_tile(w_id + d * n_waves, d);
-    QFrag f;
-    load_qfrag(f, a.ehat, a.ehat, a.B, q, g);        // (xq unused: semantic head only)
-    pin_qfrag(f);
-    KAddr kaddr;
-    kaddr.init(lane);
-    int prow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
-    ValList VL;
-    VL.init();
-    int slot = 0;
-    for (; tile < a.n_blocks; tile += n_waves) {
-        // refill the slot consumed in the previous iteration, then wait for this iteration's
-        // tile: the DEPTH-1 younger tiles (16 operations each) may stay in flight
-        issue_tile(tile + (DEPTH - 1) * n_waves, slot == 0 ? DEPTH - 1 : slot - 1);
-        if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-        QKAcc c;
-        const char* kt = my + slot * KT_BYTES;
-#ifdef RANGE_EXP_TS_NOMFMA
-        c.a0 = *reinterpret_cast<const f32x4*>(kt + lane * 16);
-#else
-        qk_mfma<false>(kt, qk_first_reads<false>(kt, kt, kaddr), kaddr, f, c,
-                       [](int) __attribute__((always_inline)) {});
-        c.fence();
-#endif
-        const int64_t row0 = (int64_t)tile * BLK;
-#ifdef RANGE_EXP_TS_NOPUSH
-        VL.v[0] += c.sem(0) + c.sem(1) + c.sem(2) + c.sem(3) + (float)row0;
-#else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                  // rows in increasing order (pi_row)
-            const int64_t row = row0 + prow[r];
-            if (row < a.n_valid) VL.push(c.sem(r), (uint32_t)row);
-        }
-#endif
-        // all LDS reads of this tile are complete (their results fed the MFMAs above) before
-        // the next iteration's DMA may overwrite the slot
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        slot = slot + 1 == DEPTH ? 0 : slot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end
-    // per-query merge: lane groups -> waves -> one list per workgroup
-    KeyList L;
-    VL.to_keys(L);
-    merge_lane_groups(L);
-    __syncthreads();                                   // ring no longer needed: reuse LDS
-    unsigned long long* sh = reinterpret_cast<unsigned long long*>(smem);   // [wave][16 q][16]
-    if (g == 0) {
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) sh[(wave * 16 + (lane & 15)) * MAX_TOPK + i] = L.k[i];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        KeyList M;
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i)
-            M.k[i] = g < WAVES ? sh[(g * 16 + (lane & 15)) * MAX_TOPK + i] : 0ull;
-        merge_lane_groups(M);
-        if (g == 0) {
-            unsigned long long* o = a.cand + (((int64_t)group * gridDim.x + blockIdx.x) * 16 + (lane & 15)) * MAX_TOPK;
-#pragma unroll
-            for (int i = 0; i < MAX_TOPK; ++i) o[i] = M.k[i];
-        }
-    }
-}
-
 // top list of the 64 sorted lists held by the lanes of one wave (no barrier: shuffles only)
 __device__ __forceinline__ void merge_wave(KeyList& L) {
     KeyList R;
@@ -706,51 +548,6 @@ __device__ __forceinline__ void merge_wave(KeyList& L) {
         if (h == m && m != 0ull) L.pop();
     }
     L = R;
-}
-
-// one workgroup per query: each thread owns one sorted candidate list (one per stream
-// workgroup, <= 512); every wave reduces its 64 lists, wave 0 reduces the per-wave results.
-__global__ __launch_bounds__(512) void merge_lists_kernel(const unsigned long long* cand, int n_parts,
-                                                          int64_t B, int k, int64_t row_offset,
-                                                          float* oval, int64_t* oidx) {
-    __shared__ unsigned long long sh[8 * MAX_TOPK];
-    const int n_wv = blockDim.x >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = blockIdx.x;
-    const int64_t group = q >> 4;
-    const int p = threadIdx.x;
-    KeyList L;
-    L.init();
-    if (p < n_parts) {
-        const unsigned long long* src = cand + ((group * n_parts + p) * 16 + (q & 15)) * MAX_TOPK;
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) L.k[i] = src[i];
-    }
-    merge_wave(L);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = L.k[i];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        KeyList M;
-        M.init();
-        if (lane < n_wv) {
-#pragma unroll
-            for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
-        }
-        merge_wave(M);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < MAX_TOPK; ++i) {
-                if (i < k) {
-                    const unsigned long long mm = M.k[i];
-                    oval[q * k + i] = mm ? topk_key_val(mm) : -INFINITY;
-                    oidx[q * k + i] = mm ? (int64_t)topk_key_row(mm) + row_offset : (int64_t)-1;
-                }
-            }
-        }
-    }
 }
 
 // theta[q] = the 16th largest of the n_parts*4 per-lane-group maxima pass 1 recorded for query q
@@ -1483,11 +1280,12 @@ __global__ void blend_kernel(const float* G, const float* H, float beta, int64_t
 }
 
 // out (B,1280) f64 = [ sum_p partial_p (f32, widened) | ehat64 ]      (range/range.py:222, :240)
+// for queries [q0, q0 + nq) of a batch of B (parts: (n_parts,B,1024), ehat64 / out: (B,..)).
 __global__ void finalize_kernel(const float* parts, int n_parts, const double* ehat64, int64_t B,
-                                double* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * 320 quads
-    if (i >= B * 320) return;
-    const int64_t q = i / 320;
+                                int64_t q0, int64_t nq, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nq * 320 quads
+    if (i >= nq * 320) return;
+    const int64_t q = q0 + i / 320;
     const int c = (int)(i % 320);
     double* o = out + q * 1280 + 4 * c;
     if (c < 256) {

@@ -8,20 +8,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/range_hip.h"
 #include "host_common.h"
+#include "host_copy.h"
 #include "attend_kernels.h"
+#include "topk_stream.h"
 #include "encoder_kernel.h"
 
 using namespace range_hip;
 using namespace range_host;
 
-// geometry of the small-batch top-k stream kernel (waves per workgroup, key tiles per wave ring)
-// (tools/topk_stream_sweep.sh: 4 x 2 is the fastest; fewer waves with deeper rings lose more in
-// per-wave list maintenance than they gain in bytes in flight)
 // waves per encoder workgroup when the hidden width is a multiple of 256 (4 or 16)
 #ifndef RANGE_ENC_WAVES
 #define RANGE_ENC_WAVES 16
@@ -32,9 +32,13 @@ using namespace range_host;
 #ifndef RANGE_TOPK_INSCAN_MAX
 #define RANGE_TOPK_INSCAN_MAX 0
 #endif
-#ifndef RANGE_TOPKS_WAVES
-#define RANGE_TOPKS_WAVES 4
-#define RANGE_TOPKS_DEPTH 2
+// range_topk_stream: query groups (of 16) sharing one pass over the keys (0 = by batch size:
+// 1 group up to 16 queries, 2 up to 32, 4 beyond), and the depth of the per-lane lists
+#ifndef RANGE_TOPKS_GROUPS
+#define RANGE_TOPKS_GROUPS 0
+#endif
+#ifndef RANGE_TOPKS_LIST
+#define RANGE_TOPKS_LIST 8
 #endif
 
 struct range_ctx {
@@ -62,11 +66,21 @@ struct range_ctx {
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
+    DevBuf<float> ws_cand_dmax;
+    DevBuf<int32_t> ws_exact_count;   // queries range_topk_stream recomputed by brute force
+    int topks_groups = RANGE_TOPKS_GROUPS;   // RANGE_TOPKS_GROUPS in the environment overrides
+    bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
     DevBuf<double> ws_ehat64;
     int last_qtiles = 0, last_splits = 0;
+    // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
+    DevBuf<double> ws_out64;
+    void* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    std::unique_ptr<HostCopyPool> pool;
     // profiling: event pairs per kernel kind
     bool profile = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[3];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[RANGE_PROF_KINDS];
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t get_event() {
         if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
@@ -75,6 +89,8 @@ struct range_ctx {
         return e;
     }
     ~range_ctx() {
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto& v : prof) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -179,6 +195,11 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
     if (!(tau_sem > 0.f)) return fail(RANGE_ERR_INVALID, "tau_sem must be > 0");
+    // the softmax statistics use the constant shift m = tau * log2(e) (scan_stats_kernel): the
+    // smallest term 2^(-2m) must stay a normal float32
+    if (tau_sem > RANGE_MAX_TAU || tau_geo > RANGE_MAX_TAU)
+        return fail(RANGE_ERR_INVALID, "temperatures above %g are not supported (the reference uses 12, 15 and 40)",
+                    (double)RANGE_MAX_TAU);
     const double LOG2E = 1.4426950408889634;
     a.keys = c->d_keys.p;
     a.xyz4 = c->d_xyz4.p;
@@ -221,6 +242,10 @@ extern "C" {
 
 int range_abi_version(void) { return RANGE_ABI_VERSION; }
 const char* range_last_error(void) { return g_err.c_str(); }
+#ifndef RANGE_BUILD_FLAGS
+#define RANGE_BUILD_FLAGS ""
+#endif
+const char* range_build_flags(void) { return RANGE_BUILD_FLAGS; }
 
 int range_create(int device, range_ctx** out) {
     if (!out) return fail(RANGE_ERR_INVALID, "out is null");
@@ -240,6 +265,8 @@ int range_create(int device, range_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* keep = std::getenv("RANGE_KEEP_LOGITS");
     c->allow_keep = !(keep && keep[0] == '0');
+    if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
+    if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     *out = c;
     return RANGE_OK;
 }
@@ -618,30 +645,61 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     hipStream_t s = (hipStream_t)stream;
     const int n_groups = (int)((B + 15) / 16);
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
-    // one workgroup per CU (its rings fill the LDS), one candidate list per workgroup, one merge
-    // thread per list (<= 512)
-    constexpr int TS_WAVES = RANGE_TOPKS_WAVES, TS_DEPTH = RANGE_TOPKS_DEPTH;
-    const int n_wg = std::max(1, std::min(c->n_cu, (n_blocks + TS_WAVES - 1) / TS_WAVES));
+    // persistent grid: one workgroup per CU (its rings fill the LDS), 4 waves each streaming
+    // their own tiles; one candidate list per (group, workgroup, query), merged by one thread
+    // each (<= 512)
+    const int n_wg = std::max(1, std::min(std::min(c->n_cu, 512), (n_blocks + 3) / 4));
     HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_wg * 16 * MAX_TOPK));
+    HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * n_wg * 16));
+    if (!c->ws_exact_count.p) {
+        HIP_TRY(c->ws_exact_count.ensure(1));
+        HIP_TRY(hipMemsetAsync(c->ws_exact_count.p, 0, sizeof(int32_t), s));
+    }
     TopkStreamArgs a{};
     a.keys = c->d_keys.p;
     a.ehat = ehat32;
     a.cand = c->ws_cand_keys.p;
+    a.dmax = c->ws_cand_dmax.p;
     a.B = B;
     a.n_valid = c->n_rows;
     a.n_blocks = n_blocks;
-    constexpr int lds = topks_lds_bytes<TS_WAVES, TS_DEPTH>();
-    int rc = set_dyn_lds(topk_stream_kernel<TS_WAVES, TS_DEPTH>, lds);
-    if (rc) return rc;
-    {
-        ProfScope ps(c, RANGE_PROF_SCAN_STATS, s);
-        hipLaunchKernelGGL((topk_stream_kernel<TS_WAVES, TS_DEPTH>), dim3((unsigned)n_wg, (unsigned)n_groups),
-                           dim3(TS_WAVES * 64), lds, s, a);
-    }
+    a.n_groups = n_groups;
+    // groups per pass: up to 2 groups (32 queries) a pass stays HBM-bound (16 FLOP per key
+    // byte against a ridge of ~20); 4 groups per pass are MFMA-bound but still take far less time
+    // than two passes
+    int G = c->topks_groups;
+    if (G != 1 && G != 2 && G != 4) G = n_groups <= 1 ? 1 : n_groups <= 2 ? 2 : 4;
+    int rc = RANGE_OK;
+#define RANGE_TOPKS_LAUNCH(GG)                                                                      \
+    do {                                                                                            \
+        rc = set_dyn_lds(topk_stream_kernel<GG, RANGE_TOPKS_LIST>, TOPKS_LDS_BYTES);                \
+        if (rc) return rc;                                                                          \
+        ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);                                                 \
+        hipLaunchKernelGGL((topk_stream_kernel<GG, RANGE_TOPKS_LIST>), dim3((unsigned)n_wg),        \
+                           dim3(256), TOPKS_LDS_BYTES, s, a);                                       \
+    } while (0)
+    if (G == 1) RANGE_TOPKS_LAUNCH(1);
+    else if (G == 2) RANGE_TOPKS_LAUNCH(2);
+    else RANGE_TOPKS_LAUNCH(4);
+#undef RANGE_TOPKS_LAUNCH
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)B), dim3(n_wg > 256 ? 512 : 256), 0, s, c->ws_cand_keys.p, n_wg, B,
-                       (int)k, c->row_offset, topk_val, topk_idx);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)B), dim3(n_wg > 256 ? 512 : 256), 0, s,
+                       c->ws_cand_keys.p, c->ws_cand_dmax.p, n_wg, B, (int)k, c->row_offset,
+                       c->d_keys.p, ehat32, c->n_rows, c->topks_force_exact ? 1 : 0,
+                       c->ws_exact_count.p, topk_val, topk_idx);
     HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+int range_topk_stream_exact_count(range_ctx* c, int64_t* count) {
+    if (!c || !count) return fail(RANGE_ERR_INVALID, "null argument");
+    *count = 0;
+    if (!c->ws_exact_count.p) return RANGE_OK;
+    DeviceGuard g(c->device);
+    int32_t v = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&v, c->ws_exact_count.p, sizeof v, hipMemcpyDeviceToHost));
+    *count = v;
     return RANGE_OK;
 }
 
@@ -789,14 +847,15 @@ int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const d
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const int64_t n = B * 320;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, partials, n_parts, ehat64, B, out);
+                       (hipStream_t)stream, partials, n_parts, ehat64, B, (int64_t)0, B, out);
     HIP_TRY(hipGetLastError());
     return RANGE_OK;
 }
 
-int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
-                  double* out, range_stream_t stream) {
-    if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
+// encode -> pass 1 (keeping its logits) -> pass 2 into the context's split slabs; the caller
+// finalizes (sums the slabs, packs with e-hat).  n_splits_out = number of slabs written.
+static int forward_to_slabs(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
+                            int* n_splits_out, range_stream_t stream) {
     if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
         return fail(RANGE_ERR_INVALID, "unknown model %d", model);
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
@@ -815,15 +874,89 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
                           nullptr, nullptr, /*keep_logits=*/1, stream);
     if (rc) return rc;
+    // pass 2 consumes the logits pass 1 kept (recomputes them if they did not fit in memory)
+    return attend_impl(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
+                       model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, n_splits_out,
+                       c->kept_B == B ? 0 : -1, stream);
+}
+
+int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
+                  double* out, range_stream_t stream) {
+    if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
     // single GPU: the finalize kernel sums the split slabs itself (same fixed order as
     // reduce_parts_kernel, so the result is bit-identical to attend + finalize)
     int n_splits = 0;
-    // pass 2 consumes the logits pass 1 kept (recomputes them if they did not fit in memory)
-    rc = attend_impl(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
-                     model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, &n_splits,
-                     c->kept_B == B ? 0 : -1, stream);
+    int rc = forward_to_slabs(c, lonlat, B, model, beta, &n_splits, stream);
     if (rc) return rc;
     return range_finalize(c, c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, out, stream);
+}
+
+int range_host_copy(range_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->pool) c->pool.reset(new HostCopyPool(HostCopyPool::default_threads()));
+    c->pool->copy(dst, src, bytes);
+    return RANGE_OK;
+}
+
+// The reference's contract (range/range.py:240): the result is a host array.  The finalize kernel
+// runs per slab of queries; each finished slab is copied to pinned staging memory on a copy stream
+// while the next is finalized, and the host threads move it into the caller's array (first-touch
+// page faults of a fresh array spread over the threads) while the DMA of the next is in flight.
+int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
+                       double* out_host, range_stream_t stream) {
+    if (!c || !lonlat || !out_host) return fail(RANGE_ERR_INVALID, "null argument");
+    int n_splits = 0;
+    int rc = forward_to_slabs(c, lonlat, B, model, beta, &n_splits, stream);
+    if (rc) return rc;
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = (size_t)RANGE_OUT_DIM * sizeof(double);
+    HIP_TRY(c->ws_out64.ensure((size_t)B * RANGE_OUT_DIM));
+    if (c->h_stage_bytes < (size_t)B * row_bytes) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->h_stage, (size_t)B * row_bytes, hipHostMallocDefault));
+        c->h_stage_bytes = (size_t)B * row_bytes;
+    }
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->pool) c->pool.reset(new HostCopyPool(HostCopyPool::default_threads()));
+    constexpr int64_t SLAB = 1024;
+    const int n_slabs = (int)((B + SLAB - 1) / SLAB);
+    std::vector<hipEvent_t> fin(n_slabs), cop(n_slabs);
+    for (int i = 0; i < n_slabs; ++i) { fin[i] = c->get_event(); cop[i] = c->get_event(); }
+    auto give_back = [&]() { for (auto e : fin) c->ev_pool.push_back(e); for (auto e : cop) c->ev_pool.push_back(e); };
+    for (int i = 0; i < n_slabs; ++i) {
+        const int64_t q0 = (int64_t)i * SLAB, nq = std::min<int64_t>(SLAB, B - q0);
+        const int64_t n = nq * 320;
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, q0, nq, c->ws_out64.p);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(fin[i], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, fin[i], 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char*)c->h_stage + q0 * row_bytes, c->ws_out64.p + q0 * RANGE_OUT_DIM,
+                               (size_t)nq * row_bytes, hipMemcpyDeviceToHost, c->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(cop[i], c->copy_stream);
+        if (e != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            give_back();
+            return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < n_slabs; ++i) {
+        const int64_t q0 = (int64_t)i * SLAB, nq = std::min<int64_t>(SLAB, B - q0);
+        hipError_t e = hipEventSynchronize(cop[i]);
+        if (e != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            give_back();
+            return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
+        }
+        c->pool->copy((char*)out_host + q0 * row_bytes, (const char*)c->h_stage + q0 * row_bytes,
+                      (size_t)nq * row_bytes);
+    }
+    give_back();
+    return RANGE_OK;
 }
 
 int range_profile_enable(range_ctx* c, int32_t on) {
@@ -838,7 +971,7 @@ int range_profile_enable(range_ctx* c, int32_t on) {
 }
 
 int range_profile_read(range_ctx* c, int32_t which, double* total_ms, int32_t* launches) {
-    if (!c || which < 0 || which > 2 || !total_ms || !launches) return fail(RANGE_ERR_INVALID, "bad argument");
+    if (!c || which < 0 || which >= RANGE_PROF_KINDS || !total_ms || !launches) return fail(RANGE_ERR_INVALID, "bad argument");
     DeviceGuard g(c->device);
     double sum = 0.0;
     for (auto& p : c->prof[which]) {

@@ -7,8 +7,9 @@ decomposes exactly over row shards:
 
     1. encode the local queries (kernel A)                       no communication
     2. all-gather the query operands e32 (B,256) and xq (B,4)     W*B*1040 B per rank, tiny
-    3. pass 1 on the local shard for ALL W*B queries -> (max, sum-exp) statistics
-    4. all-gather the statistics (W*B,4) and merge them exactly   16 B per query and rank
+    3. pass 1 on the local shard for ALL W*B queries -> softmax statistics (m, l) with the
+       constant shift m = tau*log2(e) (unit-vector logits), so the l of disjoint shards ADD
+    4. all-reduce(sum) of the l columns (W*B,2)                   8 B per query
     5. pass 2 on the local shard with the GLOBAL statistics -> partial (W*B,1024) f32; partials
        of different shards simply add because the weights are already globally normalised
     6. all-to-all: rank r receives the W partial slices of ITS queries (one direct transfer per
@@ -58,41 +59,110 @@ class ShardedRange:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_chunks = n_chunks   # None: 4 chunks when there is a peer to exchange with
+        # gathered / chunk-major / receive buffers, allocated once per (name, shape): a step then
+        # makes no allocation of its own besides the engine's outputs (torch's caching allocator)
+        self._bufs = {}
+        self._timing = False
+        self._events = []
+
+    def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
+        key = (name, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
+        return t
+
+    # -- exposed communication time ------------------------------------------------------------
+    def comm_timing(self, on: bool):
+        """``comm_timing(True)`` starts measuring, ``comm_timing(False)`` stops and returns the
+        milliseconds the COMPUTE stream spent blocked on collectives since (event pairs around
+        every point where it waits for one: the time a collective - including the wait for the
+        slowest peer - is not hidden behind this rank's kernels).  None without a GPU."""
+        if on:
+            self._events, self._timing = [], torch.cuda.is_available()
+            return None
+        if not self._timing:
+            return None
+        self._timing = False
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        self._events = []
+        return ms
+
+    def _blocked(self, fn):
+        """Run ``fn`` (something that makes the current stream wait for a collective) between two
+        events on the current stream."""
+        if not self._timing:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self._events.append((a, b))
+        return r
 
     def _staged(self, t: torch.Tensor) -> bool:
         """Device tensors over the gloo backend (several ranks sharing one GPU in tests, or a box
         without RCCL): the collective runs on host copies.  RCCL moves device memory directly."""
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
-    def _gather(self, t: torch.Tensor) -> torch.Tensor:
+    def _gather(self, t: torch.Tensor, name: str) -> torch.Tensor:
         # concatenation form (W*n, ...): accepted by both the RCCL and the gloo backend
         src = t.contiguous()
         if self._staged(t):
             src = src.cpu()
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                          device=src.device)
-        dist.all_gather_into_tensor(out, src, group=self.group)
+        out = self._buf("gather:" + name, (self.world * t.shape[0],) + tuple(t.shape[1:]), t.dtype,
+                        src.device)
+        self._blocked(lambda: dist.all_gather_into_tensor(out, src, group=self.group))
         return out.to(t.device).reshape((self.world,) + tuple(t.shape))
 
-    def _all_to_all(self, part: torch.Tensor):
+    def _all_to_all(self, part: torch.Tensor, name: str):
         """Start the exchange of a chunk's partials; returns (work, getter of the received tensor)."""
         if self._staged(part):
             src = part.cpu()
             recv = torch.empty_like(src)
             work = dist.all_to_all_single(recv, src, group=self.group, async_op=True)
             return work, (lambda: recv.to(part.device)), src
-        recv = torch.empty_like(part)
+        recv = self._buf("recv:" + name, part.shape, part.dtype, part.device)
         # one direct transfer per peer; asynchronous, so that the exchange of this chunk
         # overlaps pass 2 of the next
         work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
         return work, (lambda: recv), part
 
+    def _reduce_stats(self, stats_local: torch.Tensor) -> torch.Tensor:
+        """Global softmax statistics from the shards': every shard reports (m, l) with the SAME
+        constant shift m (range_hip.h: range_scan_stats), so the sums l of disjoint row sets
+        add - one all-reduce of the two l columns, in place of an all-gather and a merge kernel."""
+        l = stats_local[:, 1::2].contiguous()
+        if self._staged(l):
+            h = l.cpu()
+            self._blocked(lambda: dist.all_reduce(h, group=self.group))
+            l = h.to(stats_local.device)
+        else:
+            self._blocked(lambda: dist.all_reduce(l, group=self.group))
+        stats_local[:, 1::2] = l
+        return stats_local
+
     def _gather_queries(self, lonlat: torch.Tensor):
         e64, e32, xq = self.engine.encode(lonlat)
         W, B = self.world, lonlat.shape[0]
-        e32_all = self._gather(e32).reshape(W * B, e32.shape[1])
-        xq_all = self._gather(xq).reshape(W * B, xq.shape[1])
+        e32_all = self._gather(e32, "e32").reshape(W * B, e32.shape[1])
+        xq_all = self._gather(xq, "xq").reshape(W * B, xq.shape[1])
         return e64, e32_all, xq_all
+
+    def _chunk_major(self, t_all: torch.Tensor, chunks, name: str) -> torch.Tensor:
+        """(W*B, d) in rank-major order -> chunk-major order: rows [lo,hi) of EVERY rank's queries
+        form one chunk, ordered by owner rank - a contiguous range of the scanned batch whose
+        partial is again W equal slices, one per destination."""
+        if len(chunks) == 1:
+            return t_all
+        W = self.world
+        B = t_all.shape[0] // W
+        v = t_all.reshape(W, B, -1)
+        out = self._buf("cm:" + name, t_all.shape, t_all.dtype, t_all.device)
+        for lo, hi in chunks:
+            out[W * lo:W * hi].view(W, hi - lo, -1).copy_(v[:, lo:hi])
+        return out
 
     def _chunk_bounds(self, B: int):
         """Row ranges [lo,hi) of a rank's queries per chunk.  Boundaries are multiples of 64 (the
@@ -111,20 +181,14 @@ class ShardedRange:
         W, B = self.world, lonlat.shape[0]
         e64, e32_all, xq_all = self._gather_queries(lonlat)
         chunks = self._chunk_bounds(B)
-        if len(chunks) > 1:
-            # chunk-major order: rows [lo,hi) of EVERY rank's queries form one chunk, ordered by
-            # owner rank - a contiguous range of the scanned batch whose partial is again W equal
-            # slices, one per destination
-            e32_v = e32_all.reshape(W, B, -1)
-            xq_v = xq_all.reshape(W, B, -1)
-            e32_all = torch.cat([e32_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
-            xq_all = torch.cat([xq_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+        e32_all = self._chunk_major(e32_all, chunks, "e32")
+        xq_all = self._chunk_major(xq_all, chunks, "xq")
         # pass 1 on the local shard keeps its logits; pass 2 reads them back instead of
         # recomputing e . K^T (they are independent of the global statistics)
         stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
                                              keep_logits=True)
         kept = self.engine.kept_queries() == W * B
-        stats = self.engine.merge_stats(self._gather(stats_local))
+        stats = self._reduce_stats(stats_local)
         pending = []
         for lo, hi in chunks:
             first, n = W * lo, W * (hi - lo)
@@ -135,11 +199,11 @@ class ShardedRange:
                 part = self.engine.attend(e32_all[first:first + n], xq_all[first:first + n],
                                           self.tau_sem, self.tau_geo, self.beta,
                                           stats[first:first + n])
-            work, get, keep = self._all_to_all(part)
+            work, get, keep = self._all_to_all(part, f"fwd{lo}")
             pending.append((work, get, keep, lo, hi))
         outs = []
         for work, get, keep, lo, hi in pending:
-            work.wait()
+            self._blocked(work.wait)
             recv = get()
             outs.append(self.engine.finalize(recv.reshape(W, hi - lo, recv.shape[1]),
                                              e64[lo:hi].contiguous()))
@@ -160,15 +224,12 @@ class ShardedRange:
         W, B = self.world, lonlat.shape[0]
         e64, e32_all, xq_all = self._gather_queries(lonlat)
         chunks = self._chunk_bounds(B)
-        if len(chunks) > 1:
-            e32_v = e32_all.reshape(W, B, -1)
-            xq_v = xq_all.reshape(W, B, -1)
-            e32_all = torch.cat([e32_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
-            xq_all = torch.cat([xq_v[:, lo:hi].reshape(W * (hi - lo), -1) for lo, hi in chunks])
+        e32_all = self._chunk_major(e32_all, chunks, "e32")
+        xq_all = self._chunk_major(xq_all, chunks, "xq")
         stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
                                              keep_logits=True)
         kept = self.engine.kept_queries() == W * B
-        stats = self.engine.merge_stats(self._gather(stats_local))
+        stats = self._reduce_stats(stats_local)
         pending = []
         for lo, hi in chunks:
             first, n = W * lo, W * (hi - lo)
@@ -181,13 +242,13 @@ class ShardedRange:
                 else:
                     parts.append(self.engine.attend(e32_all[sl], xq_all[sl], self.tau_sem,
                                                     self.tau_geo, b, stats[sl]))
-            ex = [self._all_to_all(p) for p in parts]
+            ex = [self._all_to_all(p, f"sweep{lo}:{j}") for j, p in enumerate(parts)]
             pending.append((ex, lo, hi))
         out = torch.empty((len(betas), B, e64.shape[1] + 1024), dtype=torch.float64,
                           device=e64.device)
         for ex, lo, hi in pending:
             for work, _, _ in ex:
-                work.wait()
+                self._blocked(work.wait)
             rH, rG = ex[0][1](), ex[1][1]()
             e = e64[lo:hi].contiguous()
             for j, b in enumerate(betas):
@@ -206,7 +267,7 @@ class ShardedRange:
         packed = torch.empty((W * B, k, 3), dtype=torch.float32, device=tv.device)
         packed[:, :, 0] = tv
         packed[:, :, 1:] = ti.view(torch.float32).reshape(W * B, k, 2)   # int64 bit pattern
-        allp = self._gather(packed)                                       # the ONE all-gather
+        allp = self._gather(packed, "topk")                                    # the ONE all-gather
         sl = slice(self.rank * B, (self.rank + 1) * B)
         vals = allp[:, sl, :, 0].contiguous()
         idxs = allp[:, sl, :, 1:].contiguous().view(torch.int64).reshape(W, B, k)

@@ -114,10 +114,6 @@ class LocationEncoder(nn.Module):
             raise NotImplementedError(f"{self.location_model_name} not implemented")
         self.eval()
 
-    # nn.Module.to()/cuda() must not silently move the engine: the bank lives in the context
-    def _apply(self, fn, recurse=True):
-        return super()._apply(fn, recurse)
-
     def _coords(self, coords) -> torch.Tensor:
         if not torch.is_tensor(coords):
             coords = torch.as_tensor(np.asarray(coords))
@@ -150,14 +146,20 @@ class LocationEncoder(nn.Module):
             return torch.cat([self.engine.encode_raw(x[i:i + self.chunk_size])
                               for i in range(0, B, self.chunk_size)])
         beta = 1.0 if self._model_id == _native.MODEL_RANGE else float(self.args.beta)
-        out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
         # (B == 0: nothing to launch; the reference returns an empty (0,1280) array as well)
+        if not return_device:
+            # the reference's contract: a fresh host array (range.py:240), filled slab by slab
+            # while the device->host copies of later slabs are in flight (range_forward_host)
+            host = np.empty((B, _native.OUT_DIM), dtype=np.float64)
+            for i in range(0, B, self.chunk_size):
+                self.engine.forward_host(x[i:i + self.chunk_size], self._model_id, beta,
+                                         out=host[i:i + self.chunk_size])
+            return host
+        out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
         for i in range(0, B, self.chunk_size):
             self.engine.forward(x[i:i + self.chunk_size], self._model_id, beta,
                                 out=out[i:i + self.chunk_size])
-        if return_device:
-            return out
-        return out.cpu().numpy()
+        return out
 
     @torch.no_grad()
     def sweep(self, coords, betas, return_device: bool = False):

@@ -76,7 +76,12 @@ class EmbeddingPipeline:
 
     def _collect(self, slot: int, n: int) -> np.ndarray:
         self._copied[slot].synchronize()
-        return self._pinned[slot][:n].numpy().copy()
+        # a fresh array per batch (the reference's contract); its first-touch page faults are
+        # spread over the library's copy threads (one thread takes 12 ms per 100 MB)
+        src = self._pinned[slot][:n].numpy()
+        out = np.empty_like(src)
+        self.engine.host_copy(out, src)
+        return out
 
 
 def save_embeddings(args, train_loader, val_loader, location_model):

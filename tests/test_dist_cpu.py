@@ -43,14 +43,15 @@ class OracleShardEngine:
     def scan_stats(self, e32, xq, tau_sem, tau_geo, topk=0, keep_logits=False):
         self._kept = e32.clone() if keep_logits and self.keep_ok and not topk else None
         s, g = self._logits(e32, xq)
+        # the engine's contract (range_hip.h): constant shift m = tau*log2(e), l = sum 2^(t - m)
         st = np.zeros((s.shape[0], 4), np.float64)
         t = s * tau_sem * LOG2E
-        st[:, 0] = t.max(1); st[:, 1] = np.exp2(t - st[:, :1]).sum(1)
+        st[:, 0] = tau_sem * LOG2E; st[:, 1] = np.exp2(t - st[:, :1]).sum(1)
         if tau_geo > 0:
             t = g * tau_geo * LOG2E
-            st[:, 2] = t.max(1); st[:, 3] = np.exp2(t - st[:, 2:3]).sum(1)
+            st[:, 2] = tau_geo * LOG2E; st[:, 3] = np.exp2(t - st[:, 2:3]).sum(1)
         else:
-            st[:, 3] = 1.0
+            st[:, 2] = -1e30
         st = torch.from_numpy(st.astype(np.float32))
         if not topk:
             return st

@@ -1,0 +1,143 @@
+"""BASELINE.json's single-GPU configurations at FULL size, through the drop-in API
+(``load_model(...)(q, return_device=True)``), i.e. through the kernels and the launch geometry the
+benchmark times (pass 1 keeping its logits, pass 2 on the kept logits, split slabs summed by the
+finalize kernel):
+
+  C2  RANGE+ beta=0.5, range_db_med   (N =  50 000), 10 000 queries, top-16 indices bit-exact
+  C3  RANGE+ beta=0.5, range_db_large (N = 100 000), 100 000 queries in chunks of 16 384
+
+A dense oracle at these sizes would take minutes, so every row is checked through size-independent
+properties (planted constant value columns are reproduced - the softmax weights of each row sum
+to one over all N rows; every output lies inside the range of the bank values; e-hat rows are unit
+vectors and equal the separately encoded ones) and a 256-query sample is checked against the
+float64 oracle (2e-5), the reference's float32 op order (1e-4, the north-star tolerance) and the
+oracle's top-16.  Plus: ``bench.py --gpus 2`` started from a plain shell (two gloo ranks sharing the
+one GPU of the test box) as a subprocess.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import range_oracle as O
+from range_amd import load_model, synth
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L, H, SEED = 40, 512, 1234
+
+
+def _model(tmp_path, N):
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
+    locs, vals, keys = synth.make_bank(N, 2024)
+    vals = vals.copy()
+    vals[:, 0] = 1.0            # constant columns: reproduced iff the weights of a row sum to one
+    vals[:, 1] = -2.5
+    db = str(tmp_path / f"db{N}.npz")
+    np.savez(db, locs=locs, image_embeddings=vals, satclip_embeddings=keys)   # generate_db.py:212-214
+    m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=0.5)
+    return m, O.prep_bank(locs, vals, keys), synth.make_encoder_weights(L, H, 256, 2, SEED)
+
+
+def _check_all_rows(out, m, x, vmin, vmax):
+    assert out.shape == (x.shape[0], 1280) and out.dtype == torch.float64 and out.is_cuda
+    assert bool(torch.isfinite(out).all())
+    # float32 sums of N weights on both sides (pass 1's l, pass 2's MFMA accumulation): the
+    # worst row of 10^4..10^5 queries sits at ~40 ulp, the mean at ~7 ulp (sequential f32 sums of ~7700 terms per split)
+    assert float((out[:, 0] - 1.0).abs().max()) < 1e-5
+    assert float((out[:, 1] + 2.5).abs().max()) < 2.5e-5
+    assert float((out[:, 0] - 1.0).abs().mean()) < 3e-6
+    assert float(out[:, :1024].max()) <= vmax and float(out[:, :1024].min()) >= vmin
+    assert float((out[:, 1024:].norm(dim=1) - 1.0).abs().max()) < 1e-12
+    # the e-hat half is the encoder's output, whatever chunk / workgroup the query was in (the
+    # float64 summation order of a workgroup depends on its position, not the values beyond ~1e-15)
+    for lo in (0, x.shape[0] - 4096):
+        e64, _, _ = m.engine.encode(x[lo:lo + 4096])
+        assert float((out[lo:lo + 4096, 1024:] - e64).abs().max()) < 1e-13
+
+
+def _check_sample(out, m, q, x, obank, w, n=256):
+    idx = np.sort(np.random.default_rng(1).choice(q.shape[0], n, replace=False))
+    got = out[torch.from_numpy(idx).to(out.device)].cpu().numpy()
+    qs = q[idx]
+    e = O.encode(qs, w, L)
+    np.testing.assert_allclose(got[:, 1024:], e, rtol=0, atol=2e-12)
+    np.testing.assert_allclose(got[:, :1024], O.retrieve64(e, qs, obank, "RANGE+", 0.5), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got, O.retrieve(e, qs, obank, "RANGE+", 0.5), rtol=0, atol=1e-4)
+    # top-16 side channel of the same queries: indices equal to the float64 oracle's
+    tv, ti = m.topk(x[torch.from_numpy(idx).to(x.device)], 16)
+    s64, _ = O.logits64(e, qs, obank)
+    rv, ri = O.topk64(s64, 16)
+    np.testing.assert_allclose(tv.cpu().numpy(), rv, rtol=0, atol=3e-7)
+    ti = ti.cpu().numpy()
+    bad = np.nonzero((ti != ri).any(axis=1))[0]
+    for r in bad:   # only f32 near-ties (<= 4 ulp) may swap
+        assert np.all(np.abs(s64[r, ti[r]] - rv[r]) <= 4 * np.spacing(np.float32(1.0)))
+    assert len(bad) <= 1
+
+
+def test_c2_range_db_med_10k_queries(tmp_path):
+    N, B = synth.BANK_ROWS["range_db_med"], 10_000
+    m, obank, w = _model(tmp_path, N)
+    q = synth.make_queries(B, seed=7)
+    x = torch.from_numpy(q).to("cuda:0")
+    out = m(x, return_device=True)
+    assert m.engine.kept_queries() == B                  # pass 2 ran on the kept logits
+    qt, ns = m.engine.last_geometry()
+    assert qt == 157 and ns > 1                          # the split geometry of a 10k-query batch
+    _check_all_rows(out, m, x, float(obank.values.min()), float(obank.values.max()))
+    _check_sample(out, m, q, x, obank, w)
+    # the numpy contract (host array filled slab by slab, range_forward_host) returns the same
+    # values: bit-identical for the same batch, within split-order rounding for a sub-batch
+    host = m(x)
+    assert isinstance(host, np.ndarray) and host.dtype == np.float64
+    assert np.array_equal(host, out.cpu().numpy())
+    np.testing.assert_allclose(m(x[:3000]), host[:3000], rtol=1e-5, atol=1e-5)
+
+
+def test_c3_range_db_large_100k_queries(tmp_path):
+    N, B = synth.BANK_ROWS["range_db_large"], 100_000
+    m, obank, w = _model(tmp_path, N)
+    # queries over the whole sphere (the e-hat of high latitudes is the exact-math value, see
+    # DESIGN.md section 4; the retrieval half is compared given the oracle's own e-hat)
+    q = synth.make_queries(B, seed=7, lat_max=90.0)
+    x = torch.from_numpy(q).to("cuda:0")
+    out = m(x, return_device=True)
+    assert m.chunk_size == 16384 and m.engine.kept_queries() == B - 6 * 16384
+    _check_all_rows(out, m, x, float(obank.values.min()), float(obank.values.max()))
+    _check_sample(out, m, q, x, obank, w)
+    # one 10 000-query batch = the benchmark's launch (157 query tiles x 13 bank splits)
+    out10k = m(x[:10_000], return_device=True)
+    assert m.engine.last_geometry() == (157, 13) and m.engine.kept_queries() == 10_000
+    # (other split boundaries: float32 sums of ~10^4 terms in another order, worst element of 1.3e7 at ~40 ulp)
+    np.testing.assert_allclose(out10k.cpu().numpy(), out[:10_000].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_bench_self_launches_two_ranks():
+    """``python bench.py --gpus 2`` from a plain shell starts its own rank processes (fresh
+    children, torch.distributed.run) and relays rank 0's line.  Two gloo ranks share the one GPU
+    of the test box (RCCL needs a GPU per rank): the timing means nothing, the flow is the N>1 one."""
+    env = dict(os.environ, RANGE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--bank", "range_db_med"],
+                       env=env, cwd=REPO, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "strong"
+    assert r["config"]["queries_total"] == 10_000 and r["config"]["queries_per_gpu"] == 5_000
+    assert r["dist"]["backend"] == "gloo" and r["dist"]["world_size"] == 2
+    assert r["parity_max_abs"] < 1e-4
+    assert r["weak"]["queries_per_gpu"] == 10_000
+    # a rank that fails makes the launcher exit non-zero
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--queries", "10001"],
+                       env=env, cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0

@@ -435,6 +435,51 @@ def test_topk_stream_kernel_vs_oracle(N, B, k):
     assert torch.equal(ti, ti2) and torch.equal(tv, tv2)
 
 
+def test_topk_stream_exact_fallback(monkeypatch):
+    """range_topk_stream keeps short per-lane lists and recomputes a query by brute force when a
+    dropped value could belong to its top-k.  (i) forced on every query the brute-force path gives
+    bit-identical values and indices (its fmaf chain is the MFMA chain); (ii) a bank made of 40
+    copies of a few rows puts more equal-valued top members into single lanes than a list holds:
+    the check must fire and the result must still equal the oracle's (ties -> lower row)."""
+    N, B, k = 20000, 20, 16
+    bank, obank, w, enc, q, e = _synthetic_case(N, B)
+    e32 = _dev(e, torch.float32)
+    eng = _engine(None, bank)
+    tv, ti = eng.topk_stream(e32, k)
+    assert eng.topk_stream_exact_count() == 0
+    monkeypatch.setenv("RANGE_TOPKS_FORCE_EXACT", "1")
+    engx = _engine(None, bank)
+    monkeypatch.delenv("RANGE_TOPKS_FORCE_EXACT")
+    tvx, tix = engx.topk_stream(e32, k)
+    assert engx.topk_stream_exact_count() == B
+    assert torch.equal(ti, tix) and torch.equal(tv, tvx)
+    # (ii) duplicates: rows r, r + 16*1024*t sit in the same lane of the same wave (a wave's tiles
+    # are 1024 = the wave count apart): 12 copies of a query's best row in ONE lane's rows
+    n_waves = 4 * 256
+    N2 = 16 * n_waves * 12 + 400
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((N2, 256)).astype(np.float32)
+    big /= np.linalg.norm(big, axis=1, keepdims=True)
+    qs = np.zeros((4, 256), np.float32)
+    for b in range(4):
+        base = 16 * b + 5
+        for t in range(12):
+            big[base + 16 * n_waves * t] = big[base]
+        qs[b] = big[base]
+    vals = rng.standard_normal((N2, 1024)).astype(np.float32)
+    xyz = rng.standard_normal((N2, 3)).astype(np.float32)
+    eng2 = _engine()
+    eng2.set_bank(big, vals, xyz)
+    tv2, ti2 = eng2.topk_stream(_dev(qs), k)
+    assert eng2.topk_stream_exact_count() == 4
+    s64 = qs.astype(np.float64) @ big.astype(np.float64).T
+    rv, ri = O.topk64(s64, k)
+    ti2 = ti2.cpu().numpy()
+    for b in range(4):   # the 12 copies first, lower rows first
+        assert np.array_equal(ti2[b, :12], 16 * b + 5 + 16 * n_waves * np.arange(12))
+    np.testing.assert_allclose(tv2.cpu().numpy(), rv, rtol=0, atol=6e-7)   # f32 dot of 256 terms near 1.0
+
+
 def test_encoder_edge_coordinates():
     """Poles, antimeridian, equator/prime-meridian crossings, out-of-range wrap: the fused encoder
     must agree with the float64 oracle everywhere (the recurrence is stable at the poles, where the
