@@ -332,7 +332,7 @@ def main():
     scan = None
     host_contract = None
     if world == 1 and not sharded and not a.no_extras:
-        scan = scan_roofline(eng, synth, torch, dev, N)
+        scan = scan_roofline(eng, synth, torch, dev, N, bank)
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
 
     if rank == 0:
@@ -427,30 +427,54 @@ def main():
         dist.destroy_process_group()
 
 
-def scan_roofline(eng, synth, torch, dev, N):
+def scan_roofline(eng, synth, torch, dev, N, bank):
     """The HBM-bound regime of the path: the keys-only top-k scan (``range_topk_stream``) for a
-    handful of queries.  One pass streams the N x 1 KB key rows once per 16 queries; achieved =
-    passes x N x 1024 B / the kernel's mean launch time (HIP events on the launch stream)."""
+    handful of queries.  One pass streams the N x 1 KB key rows once for 16 queries - or for 32:
+    two groups of 16 share a pass (16 FLOP per key byte, about at the ridge; faster per query,
+    no longer purely HBM-bound).  achieved = passes x N x 1024 B / time per launch of the stream
+    kernel, launched 20 times back to back between one pair of HIP events on the launch stream
+    (event pairs around single launches are also given: they add ~5 us of dispatch latency to a
+    ~20 us kernel).  The last entry forces one group per pass for 64 queries (4 passes in one
+    launch): the pure streaming regime at a length where launch ramp-up no longer dominates."""
     from range_amd import _native
     out = []
-    for nq in (16, 64):
+    eng1 = None
+    for nq, force_single in ((16, False), (32, False), (64, False), (64, True)):
+        e = eng
+        if force_single:
+            os.environ["RANGE_TOPKS_GROUPS"] = "1"       # read at range_create
+            try:
+                e = eng1 = _native.HipEngine(dev)
+            finally:
+                os.environ.pop("RANGE_TOPKS_GROUPS", None)
+            e.set_bank(bank.keys, bank.values, bank.xyz, 0)
         x = torch.from_numpy(synth.make_queries(nq, seed=11)).to(dev)
         _, e32, _ = eng.encode(x)
         for _ in range(5):
-            eng.topk_stream(e32, 16)
-        eng.profile_enable(True)
-        reps = 30
-        for _ in range(reps):
-            eng.topk_stream(e32, 16)
+            e.topk_stream(e32, 16)
+        e.profile_enable(True)
+        for _ in range(20):
+            e.topk_stream(e32, 16)
         torch.cuda.synchronize(dev)
-        ms, n = eng.profile_read(_native.PROF_TOPK_STREAM)
-        eng.profile_enable(False)
-        passes = (nq + 15) // 16
+        ms, n = e.profile_read(_native.PROF_TOPK_STREAM)
+        mms, mn = e.profile_read(_native.PROF_TOPK_MERGE)
+        e.profile_enable(False)
+        us = min(e.topk_stream_timed(e32, 16, 20)[2] for _ in range(3))
+        groups = (nq + 15) // 16
+        per_pass = 1 if (groups <= 1 or force_single) else 2    # range_topk_stream's choice (range_hip.hip)
+        passes = (groups + per_pass - 1) // per_pass
         byts = passes * N * KEY_ROW_BYTES
-        us = ms / n * 1e3
-        out.append({"kernel": "topk_stream_kernel", "queries": nq, "passes": passes, "bytes": byts,
-                    "avg_us": us, "launches": n, "achieved_TBps": byts / (us * 1e-6) / 1e12,
-                    "peak_TBps": PEAK_HBM_GBS / 1e3, "frac": byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS})
+        out.append({"kernel": f"topk_stream_kernel<{per_pass} group(s) of 16 queries per pass>",
+                    "queries": nq, "passes": passes, "bytes": byts, "avg_us": us,
+                    "avg_us_source": "20 back-to-back launches between one HIP event pair",
+                    "avg_us_event_pair_per_launch": ms / n * 1e3,
+                    "achieved_TBps": byts / (us * 1e-6) / 1e12, "peak_TBps": PEAK_HBM_GBS / 1e3,
+                    "frac": byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                    "product_path": not force_single,
+                    "merge_kernel_avg_us_event_pair": mms / mn * 1e3,
+                    "exact_fallback_queries": e.topk_stream_exact_count()})
+    if eng1 is not None:
+        eng1.close()
     return out
 
 

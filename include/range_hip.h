@@ -160,6 +160,12 @@ int64_t range_kept_queries(const range_ctx* ctx);
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);
+/* Bench harness: the same call with the stream kernel launched `repeats` (>= 2) times back to back
+ * between ONE pair of HIP events on `stream` (a pair around a single ~20 us launch adds ~5 us of
+ * dispatch latency to it); *avg_us = time per launch.  Synchronises with the stream. */
+int range_topk_stream_timed(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
+                            float* topk_val_dev, int64_t* topk_idx_dev, int32_t repeats,
+                            float* avg_us, range_stream_t stream);
 
 /* Exact merge of per-shard statistics (row-sharded bank): parts_dev is (n_parts,B,4) as written
  * by range_scan_stats on each shard (e.g. after an all-gather); out_dev is (B,4). */
@@ -234,7 +240,7 @@ int range_last_attend_geometry(const range_ctx* ctx, int32_t* n_query_tiles, int
  * collecting (and clears earlier samples); range_profile_read synchronises with the recorded
  * events and returns the summed duration and the number of launches of one kernel. */
 enum { RANGE_PROF_ENCODER = 0, RANGE_PROF_SCAN_STATS = 1, RANGE_PROF_ATTEND = 2,
-       RANGE_PROF_TOPK_STREAM = 3, RANGE_PROF_KINDS = 4 };
+       RANGE_PROF_TOPK_STREAM = 3, RANGE_PROF_TOPK_MERGE = 4, RANGE_PROF_KINDS = 5 };
 int range_profile_enable(range_ctx* ctx, int32_t on);
 int range_profile_read(range_ctx* ctx, int32_t which, double* total_ms, int32_t* launches);
 

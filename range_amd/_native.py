@@ -22,7 +22,7 @@ KEY_DIM, VAL_DIM, OUT_DIM = 256, 1024, 1280
 SH_ANALYTIC, SH_CLOSED_FORM = 0, 1
 MODEL_RANGE, MODEL_RANGE_PLUS = 0, 1
 MAX_TOPK = 16
-PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND, PROF_TOPK_STREAM = 0, 1, 2, 3   # range_profile_read(which)
+PROF_ENCODER, PROF_SCAN_STATS, PROF_ATTEND, PROF_TOPK_STREAM, PROF_TOPK_MERGE = 0, 1, 2, 3, 4
 COORD_DIRECT, COORD_CARTESIAN3D, COORD_WRAP = 0, 1, 2   # range_coord_features(mode)
 COORD_DIMS = {COORD_DIRECT: 2, COORD_CARTESIAN3D: 3, COORD_WRAP: 4}
 
@@ -34,7 +34,7 @@ SYMBOLS = (
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
-    "range_host_copy", "range_topk_stream_exact_count",
+    "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
 )
 
 
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
     lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.range_topk_stream_exact_count.argtypes = [vp, C.POINTER(i64)]
+    lib.range_topk_stream_timed.argtypes = [vp, vp, i64, i32, vp, vp, i32, C.POINTER(f32), vp]
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)
@@ -277,6 +278,19 @@ class HipEngine:
         _check(self.lib, self.lib.range_topk_stream(self._h, e32.data_ptr(), B, k, tv.data_ptr(),
                                                     ti.data_ptr(), self._stream()))
         return tv, ti
+
+    def topk_stream_timed(self, e32: torch.Tensor, k: int, repeats: int = 20):
+        """topk_stream with the stream kernel launched ``repeats`` times back to back between one
+        pair of events: returns (values, indices, microseconds per stream-kernel launch)."""
+        self._t(e32, torch.float32, (KEY_DIM,))
+        B = e32.shape[0]
+        tv = self._empty((B, k), torch.float32)
+        ti = self._empty((B, k), torch.int64)
+        us = C.c_float()
+        _check(self.lib, self.lib.range_topk_stream_timed(self._h, e32.data_ptr(), B, k, tv.data_ptr(),
+                                                          ti.data_ptr(), repeats, C.byref(us),
+                                                          self._stream()))
+        return tv, ti, us.value
 
     def topk_stream_exact_count(self) -> int:
         """Queries topk_stream recomputed by brute force (its short per-lane lists could have

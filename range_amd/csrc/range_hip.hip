@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,7 +39,7 @@ using namespace range_host;
 #define RANGE_TOPKS_GROUPS 0
 #endif
 #ifndef RANGE_TOPKS_LIST
-#define RANGE_TOPKS_LIST 8
+#define RANGE_TOPKS_LIST 4
 #endif
 
 struct range_ctx {
@@ -78,6 +79,7 @@ struct range_ctx {
     size_t h_stage_bytes = 0;
     hipStream_t copy_stream = nullptr;
     std::unique_ptr<HostCopyPool> pool;
+    bool host_timing = false;   // RANGE_HOST_TIMING=1: phase times of range_forward_host on stderr
     // profiling: event pairs per kernel kind
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[RANGE_PROF_KINDS];
@@ -265,6 +267,7 @@ int range_create(int device, range_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* keep = std::getenv("RANGE_KEEP_LOGITS");
     c->allow_keep = !(keep && keep[0] == '0');
+    if (const char* e = std::getenv("RANGE_HOST_TIMING")) c->host_timing = e[0] == '1';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     *out = c;
@@ -635,8 +638,11 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     return RANGE_OK;
 }
 
-int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
-                      int64_t* topk_idx, range_stream_t stream) {
+// repeats > 1 (range_topk_stream_timed): the stream kernel is launched `repeats` times back to
+// back between ONE pair of events (identical launches, identical results) and *avg_us receives
+// the time per launch; the merge kernel runs once, afterwards.
+static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
+                            int64_t* topk_idx, int repeats, float* avg_us, range_stream_t stream) {
     if (!c || !ehat32 || !topk_val || !topk_idx) return fail(RANGE_ERR_INVALID, "null argument");
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
     if (B <= 0 || k <= 0 || k > MAX_TOPK) return fail(RANGE_ERR_INVALID, "bad B or k");
@@ -646,11 +652,12 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     const int n_groups = (int)((B + 15) / 16);
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
     // persistent grid: one workgroup per CU (its rings fill the LDS), 4 waves each streaming
-    // their own tiles; one candidate list per (group, workgroup, query), merged by one thread
-    // each (<= 512)
-    const int n_wg = std::max(1, std::min(std::min(c->n_cu, 512), (n_blocks + 3) / 4));
-    HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_wg * 16 * MAX_TOPK));
-    HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * n_wg * 16));
+    // their own tiles; one candidate list per (group, wave, query), merged by one thread each
+    constexpr int LIST = RANGE_TOPKS_LIST;
+    const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + 3) / 4));
+    const int n_lists = n_wg * 4;
+    HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_lists * 16 * LIST));
+    HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * n_lists * 16));
     if (!c->ws_exact_count.p) {
         HIP_TRY(c->ws_exact_count.ensure(1));
         HIP_TRY(hipMemsetAsync(c->ws_exact_count.p, 0, sizeof(int32_t), s));
@@ -664,31 +671,104 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     a.n_valid = c->n_rows;
     a.n_blocks = n_blocks;
     a.n_groups = n_groups;
-    // groups per pass: up to 2 groups (32 queries) a pass stays HBM-bound (16 FLOP per key
-    // byte against a ridge of ~20); 4 groups per pass are MFMA-bound but still take far less time
-    // than two passes
+#ifdef RANGE_EXP_TS_STAMPS
+    static DevBuf<unsigned long long> stamps_buf;
+    HIP_TRY(stamps_buf.ensure((size_t)n_lists * 8));
+    HIP_TRY(hipMemsetAsync(stamps_buf.p, 0, (size_t)n_lists * 64, s));
+    a.stamps = stamps_buf.p;
+#endif
+    // query groups sharing one pass over the keys: 2 groups (32 queries) are still HBM-bound (16
+    // FLOP per key byte against a ridge of ~20) and take the time of 1
     int G = c->topks_groups;
-    if (G != 1 && G != 2 && G != 4) G = n_groups <= 1 ? 1 : n_groups <= 2 ? 2 : 4;
+    if (G != 1 && G != 2) G = n_groups <= 1 ? 1 : 2;
     int rc = RANGE_OK;
 #define RANGE_TOPKS_LAUNCH(GG)                                                                      \
     do {                                                                                            \
-        rc = set_dyn_lds(topk_stream_kernel<GG, RANGE_TOPKS_LIST>, TOPKS_LDS_BYTES);                \
+        rc = set_dyn_lds(topk_stream_kernel<GG, LIST>, TOPKS_LDS_BYTES);                            \
         if (rc) return rc;                                                                          \
         ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);                                                 \
-        hipLaunchKernelGGL((topk_stream_kernel<GG, RANGE_TOPKS_LIST>), dim3((unsigned)n_wg),        \
-                           dim3(256), TOPKS_LDS_BYTES, s, a);                                       \
+        hipLaunchKernelGGL((topk_stream_kernel<GG, LIST>), dim3((unsigned)n_wg), dim3(256),         \
+                           TOPKS_LDS_BYTES, s, a);                                                  \
     } while (0)
-    if (G == 1) RANGE_TOPKS_LAUNCH(1);
-    else if (G == 2) RANGE_TOPKS_LAUNCH(2);
-    else RANGE_TOPKS_LAUNCH(4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (repeats > 1) {
+        ev0 = c->get_event();
+        ev1 = c->get_event();
+        HIP_TRY(hipEventRecord(ev0, s));
+    }
+    for (int rep = 0; rep < std::max(1, repeats); ++rep) {
+        if (G == 1) RANGE_TOPKS_LAUNCH(1);
+        else RANGE_TOPKS_LAUNCH(2);
+    }
 #undef RANGE_TOPKS_LAUNCH
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)B), dim3(n_wg > 256 ? 512 : 256), 0, s,
-                       c->ws_cand_keys.p, c->ws_cand_dmax.p, n_wg, B, (int)k, c->row_offset,
-                       c->d_keys.p, ehat32, c->n_rows, c->topks_force_exact ? 1 : 0,
-                       c->ws_exact_count.p, topk_val, topk_idx);
+    if (repeats > 1) {
+        HIP_TRY(hipEventRecord(ev1, s));
+        HIP_TRY(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        if (avg_us) *avg_us = ms * 1e3f / (float)repeats;
+        c->ev_pool.push_back(ev0);
+        c->ev_pool.push_back(ev1);
+    }
+#ifdef RANGE_EXP_TS_STAMPS
+    if (std::getenv("RANGE_TOPKS_STAMPS")) {   // per stamp: earliest / median / latest wave, us after the first wave's start
+        std::vector<unsigned long long> h((size_t)n_lists * 8);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(h.data(), stamps_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < n_lists; ++w) t0 = std::min(t0, h[(size_t)w * 8]);
+        std::fprintf(stderr, "topk_stream stamps (us: min med max)");
+        for (int i = 0; i < 7; ++i) {
+            std::vector<double> v;
+            for (int w = 0; w < n_lists; ++w) v.push_back((double)(h[(size_t)w * 8 + i] - t0) * 0.01);
+            std::sort(v.begin(), v.end());
+            std::fprintf(stderr, " | %d: %.1f %.1f %.1f", i, v.front(), v[v.size() / 2], v.back());
+        }
+        std::fprintf(stderr, "\n  end of tiles (stamp 4) by blockIdx %% 8:");
+        for (int x = 0; x < 8; ++x) {
+            std::vector<double> v;
+            for (int w = 0; w < n_lists; ++w) if ((w / 4) % 8 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            std::sort(v.begin(), v.end());
+            std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
+        }
+        std::fprintf(stderr, "\n  by blockIdx / 32:");
+        for (int x = 0; x < (n_wg + 31) / 32; ++x) {
+            std::vector<double> v;
+            for (int w = 0; w < n_lists; ++w) if ((w / 4) / 32 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            std::sort(v.begin(), v.end());
+            std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
+        }
+        std::fprintf(stderr, "\n  by wave in workgroup:");
+        for (int x = 0; x < 4; ++x) {
+            std::vector<double> v;
+            for (int w = 0; w < n_lists; ++w) if (w % 4 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            std::sort(v.begin(), v.end());
+            std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
+        }
+        std::fprintf(stderr, "\n");
+    }
+#endif
+    {
+        ProfScope ps(c, RANGE_PROF_TOPK_MERGE, s);
+        hipLaunchKernelGGL(topk_merge_kernel<LIST>, dim3((unsigned)B), dim3((unsigned)((n_lists + 63) / 64 * 64)),
+                           0, s, c->ws_cand_keys.p, c->ws_cand_dmax.p, n_lists, B, (int)k, c->row_offset,
+                           c->d_keys.p, ehat32, c->n_rows, c->topks_force_exact ? 1 : 0,
+                           c->ws_exact_count.p, topk_val, topk_idx);
+    }
     HIP_TRY(hipGetLastError());
     return RANGE_OK;
+}
+
+int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
+                      int64_t* topk_idx, range_stream_t stream) {
+    return topk_stream_impl(c, ehat32, B, k, topk_val, topk_idx, 1, nullptr, stream);
+}
+
+int range_topk_stream_timed(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
+                            int64_t* topk_idx, int32_t repeats, float* avg_us, range_stream_t stream) {
+    if (repeats < 2 || !avg_us) return fail(RANGE_ERR_INVALID, "repeats must be >= 2 and avg_us non-null");
+    return topk_stream_impl(c, ehat32, B, k, topk_val, topk_idx, repeats, avg_us, stream);
 }
 
 int range_topk_stream_exact_count(range_ctx* c, int64_t* count) {
@@ -905,12 +985,18 @@ int range_host_copy(range_ctx* c, void* dst, const void* src, size_t bytes) {
 int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
                        double* out_host, range_stream_t stream) {
     if (!c || !lonlat || !out_host) return fail(RANGE_ERR_INVALID, "null argument");
-    int n_splits = 0;
-    int rc = forward_to_slabs(c, lonlat, B, model, beta, &n_splits, stream);
-    if (rc) return rc;
+    if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
+        return fail(RANGE_ERR_INVALID, "unknown model %d", model);
+    if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
     DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = (hipStream_t)stream;
+    const auto t_begin = std::chrono::steady_clock::now();
     const size_t row_bytes = (size_t)RANGE_OUT_DIM * sizeof(double);
+    HIP_TRY(c->ws_ehat64.ensure((size_t)B * 256));
+    HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
+    HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
+    HIP_TRY(c->ws_stats.ensure((size_t)B * 4));
     HIP_TRY(c->ws_out64.ensure((size_t)B * RANGE_OUT_DIM));
     if (c->h_stage_bytes < (size_t)B * row_bytes) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -921,41 +1007,78 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->pool) c->pool.reset(new HostCopyPool(HostCopyPool::default_threads()));
+
+    const float tau_sem = model == RANGE_MODEL_RANGE ? 15.0f : 12.0f;   // range.py:103, 108
+    const float tau_geo = model == RANGE_MODEL_RANGE ? 0.0f : 40.0f;    // range.py:109
+    const float bt = model == RANGE_MODEL_RANGE ? 1.0f : beta;
+    int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
+    if (rc) return rc;
+    rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
+                          nullptr, nullptr, /*keep_logits=*/1, stream);
+    if (rc) return rc;
+    const bool kept = c->kept_B == B;
+
+    // Pass 2 runs in `n_parts` launches over consecutive query ranges (boundaries on query
+    // tiles): the device->host copy and the host fill of a part overlap pass 2 of the next, so
+    // only the last part's copy is exposed.  (More, smaller launches fill the chip's rounds less
+    // well - about 1 % per extra launch at this size - so large batches take 2 parts, not 8.)
+    const int n_parts = B >= 4096 ? 2 : 1;
     constexpr int64_t SLAB = 1024;
-    const int n_slabs = (int)((B + SLAB - 1) / SLAB);
-    std::vector<hipEvent_t> fin(n_slabs), cop(n_slabs);
-    for (int i = 0; i < n_slabs; ++i) { fin[i] = c->get_event(); cop[i] = c->get_event(); }
-    auto give_back = [&]() { for (auto e : fin) c->ev_pool.push_back(e); for (auto e : cop) c->ev_pool.push_back(e); };
-    for (int i = 0; i < n_slabs; ++i) {
-        const int64_t q0 = (int64_t)i * SLAB, nq = std::min<int64_t>(SLAB, B - q0);
-        const int64_t n = nq * 320;
-        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                           c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, q0, nq, c->ws_out64.p);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(fin[i], s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, fin[i], 0);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync((char*)c->h_stage + q0 * row_bytes, c->ws_out64.p + q0 * RANGE_OUT_DIM,
-                               (size_t)nq * row_bytes, hipMemcpyDeviceToHost, c->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(cop[i], c->copy_stream);
-        if (e != hipSuccess) {
-            (void)hipDeviceSynchronize();
-            give_back();
-            return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
+    struct Slab { int64_t q0, nq; hipEvent_t fin, cop; };
+    std::vector<Slab> slabs;
+    auto give_back = [&]() { for (auto& sl : slabs) { c->ev_pool.push_back(sl.fin); c->ev_pool.push_back(sl.cop); } };
+    hipError_t e = hipSuccess;
+    for (int part = 0; part < n_parts && e == hipSuccess; ++part) {
+        const int64_t p0 = ((B * part / n_parts) + QTILE / 2) / QTILE * QTILE;
+        const int64_t p1 = part + 1 == n_parts ? B : ((B * (part + 1) / n_parts) + QTILE / 2) / QTILE * QTILE;
+        if (p1 <= p0) continue;
+        int n_splits = 0;
+        rc = attend_impl(c, c->ws_ehat32.p + p0 * 256, c->ws_xq.p + p0 * 4, p1 - p0, tau_sem, tau_geo, bt,
+                         c->ws_stats.p + p0 * 4, nullptr, &n_splits, kept ? p0 : -1, stream);
+        if (rc) { (void)hipDeviceSynchronize(); give_back(); return rc; }
+        // finalize per slab (the split slabs of this part are overwritten by the next part's pass 2,
+        // which is behind these kernels in stream order)
+        for (int64_t q0 = p0; q0 < p1 && e == hipSuccess; q0 += SLAB) {
+            Slab sl{q0, std::min<int64_t>(SLAB, p1 - q0), c->get_event(), c->get_event()};
+            slabs.push_back(sl);
+            const int64_t n = sl.nq * 320;
+            hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               c->ws_slabs.p, n_splits, c->ws_ehat64.p + p0 * 256, p1 - p0, q0 - p0, sl.nq,
+                               c->ws_out64.p + p0 * RANGE_OUT_DIM);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(sl.fin, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, sl.fin, 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync((char*)c->h_stage + q0 * row_bytes, c->ws_out64.p + q0 * RANGE_OUT_DIM,
+                                   (size_t)sl.nq * row_bytes, hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(sl.cop, c->copy_stream);
         }
     }
-    for (int i = 0; i < n_slabs; ++i) {
-        const int64_t q0 = (int64_t)i * SLAB, nq = std::min<int64_t>(SLAB, B - q0);
-        hipError_t e = hipEventSynchronize(cop[i]);
-        if (e != hipSuccess) {
-            (void)hipDeviceSynchronize();
-            give_back();
-            return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
-        }
-        c->pool->copy((char*)out_host + q0 * row_bytes, (const char*)c->h_stage + q0 * row_bytes,
-                      (size_t)nq * row_bytes);
+    const auto t_enq = std::chrono::steady_clock::now();
+    double wait_s = 0.0, copy_s = 0.0;
+    for (auto& sl : slabs) {
+        if (e != hipSuccess) break;
+        const auto w0 = std::chrono::steady_clock::now();
+        e = hipEventSynchronize(sl.cop);
+        const auto w1 = std::chrono::steady_clock::now();
+        if (e != hipSuccess) break;
+        c->pool->copy((char*)out_host + sl.q0 * row_bytes, (const char*)c->h_stage + sl.q0 * row_bytes,
+                      (size_t)sl.nq * row_bytes);
+        const auto w2 = std::chrono::steady_clock::now();
+        wait_s += std::chrono::duration<double>(w1 - w0).count();
+        copy_s += std::chrono::duration<double>(w2 - w1).count();
+    }
+    if (e != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        give_back();
+        return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
     }
     give_back();
+    if (c->host_timing)
+        std::fprintf(stderr, "range_forward_host B=%lld: enqueue %.2f ms, waiting for slabs %.2f ms, host fill %.2f ms "
+                     "(%d threads), total %.2f ms\n", (long long)B,
+                     std::chrono::duration<double>(t_enq - t_begin).count() * 1e3, wait_s * 1e3, copy_s * 1e3,
+                     c->pool->size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     return RANGE_OK;
 }
 

@@ -34,20 +34,27 @@ namespace range_hip {
 struct TopkStreamArgs {
     const float* keys;          // (n_pad,256)
     const float* ehat;          // (B,256)
-    unsigned long long* cand;   // (n_groups, n_wg, 16 queries, 16) keys, sorted descending, 0 = empty
-    float* dmax;                // (n_groups, n_wg, 16 queries) largest value a lane list dropped
+    unsigned long long* cand;   // (n_groups, 16 queries, n_waves, L) keys, sorted descending, 0 = empty
+    float* dmax;                // (n_groups, 16 queries, n_waves) largest value dropped on the way
     int64_t B;
     int64_t n_valid;
     int32_t n_blocks;
     int32_t n_groups;           // ceil(B / 16)
+    unsigned long long* stamps; // RANGE_EXP_TS_STAMPS builds: 8 s_memrealtime stamps per wave
 };
+
+#ifdef RANGE_EXP_TS_STAMPS   // tuning only: where a wave's time goes (100 MHz real-time counter)
+#define RANGE_TS_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(size_t)w_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RANGE_TS_STAMP(i) do { } while (0)
+#endif
 
 #ifndef RANGE_TOPKS_VALU_PER_MFMA
 #define RANGE_TOPKS_VALU_PER_MFMA 4
 #endif
-constexpr int TOPKS_DEPTH = 2;                                       // ring slots per wave
-constexpr int TOPKS_SCRATCH_BYTES = 4 * 16 * MAX_TOPK * 8 + 4 * 16 * 4;   // cross-wave merge
-constexpr int TOPKS_LDS_BYTES = 4 * TOPKS_DEPTH * BLK * KEY_DIM * 4 + TOPKS_SCRATCH_BYTES;
+constexpr int TOPKS_DEPTH = 2;      // ring slots per wave
+constexpr int TOPKS_SG = 4;         // groups whose lists a wave carries through consecutive passes
+constexpr int TOPKS_LDS_BYTES = 4 * TOPKS_DEPTH * BLK * KEY_DIM * 4;
 
 // Sorted (descending) list of the L best (value, row) a lane has met, plus the largest value it
 // has let go.  push() is branch-free: the new value replaces the last entry if it is larger and
@@ -77,36 +84,71 @@ struct ShortList {
             v[i - 1] = hv; v[i] = lv; row[i - 1] = hr; row[i] = lr;
         }
     }
-    __device__ __forceinline__ void to_keys(KeyList& K) const {
-#pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i)
-            K.k[i] = (i < L && row[i < L ? i : 0] != 0xFFFFFFFFu) ? topk_key(v[i < L ? i : 0], row[i < L ? i : 0]) : 0ull;
-    }
 };
+
+// The 4 lanes (j, g = 0..3) of a query each hold a sorted list of L keys: afterwards every one of
+// them holds the sorted L best of the union, and `drop` the largest key that did not make it.
+// Two rounds (lane ^ 16, lane ^ 32) of a bitonic merge: c[i] = max(a[i], b[L-1-i]) are the L
+// largest of two descending lists and form a bitonic sequence, which log2(L) stages of
+// compare-exchanges sort.  No serial extraction loop: ~300 instructions for L = 8.
+template <int L>
+__device__ __forceinline__ void merge4_short(unsigned long long (&k)[L], unsigned long long& drop) {
+    static_assert(L == 4 || L == 8 || L == 16, "power-of-two list");
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        unsigned long long p[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) p[i] = shfl_xor_u64(k[L - 1 - i], off);
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const bool up = k[i] > p[i];
+            const unsigned long long lo = up ? p[i] : k[i];
+            k[i] = up ? k[i] : p[i];
+            drop = lo > drop ? lo : drop;
+        }
+#pragma unroll
+        for (int d = L / 2; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                if ((i & d) == 0) {
+                    const unsigned long long a = k[i], b = k[i + d];
+                    k[i] = a > b ? a : b;
+                    k[i + d] = a > b ? b : a;
+                }
+            }
+        }
+    }
+}
 
 template <int G, int L>
 __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
+    static_assert(TOPKS_SG % G == 0, "groups per pass must divide the supergroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
     constexpr int DEPTH = TOPKS_DEPTH;
+    constexpr int PPS = TOPKS_SG / G;                          // passes per supergroup
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * DEPTH * KT_BYTES;
     const char* my = smem + wave * DEPTH * KT_BYTES;
-    unsigned long long* sh_keys = reinterpret_cast<unsigned long long*>(smem + 4 * DEPTH * KT_BYTES);
-    float* sh_dmax = reinterpret_cast<float*>(smem + 4 * DEPTH * KT_BYTES + 4 * 16 * MAX_TOPK * 8);
 
     const int n_waves = gridDim.x * 4;
     const int w_id = blockIdx.x * 4 + wave;
+    // this wave's tiles: w_id, w_id + n_waves, ... once per pass (T per pass, the last one of a
+    // pass possibly past the bank: fetched as the bank's last tile, never consumed).  (Dealing a
+    // workgroup's tiles to its 4 waves through a counter in LDS was measured: the spread of the
+    // waves' finishing times is between XCDs and CUs, not inside a workgroup, and did not shrink.)
     const int T = (a.n_blocks + n_waves - 1) / n_waves;        // tiles per wave and pass
-    const int n_pass = (a.n_groups + G - 1) / G;
+    const int n_pass = (a.n_groups + G - 1) / G;               // passes over the keys, all supergroups
+    const int n_sg = (a.n_groups + TOPKS_SG - 1) / TOPKS_SG;
     const int total = n_pass * T;                              // this wave's tile sequence
     const int last = a.n_blocks - 1;
+    RANGE_TS_STAMP(0);
     // one tile = 16 rows = 16 DMA instructions (4 groups of 4 rows, swizzled source: chunk c of
     // row R lands at chunk position c ^ R, which makes the ds_read_b128 below conflict-free).
-    // Sequence positions past the end (and tiles past the bank: the ragged last round) fetch the
-    // bank's last tile again - never consumed - so that every wait below is a constant.
+    // Sequence positions past the end fetch the bank's last tile again - never consumed - so
+    // that every wait below is a constant.
     auto issue_seq = [&](int k) __attribute__((always_inline)) {
         const int i = k < total ? k % T : T - 1;
         const int tile = w_id + i * n_waves;
@@ -122,207 +164,248 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
     };
     issue_seq(0);
     issue_seq(1);
+    RANGE_TS_STAMP(1);
 
     KAddr kaddr;
     kaddr.init(lane);
     uint32_t prow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
+    const uint32_t n_valid32 = (uint32_t)a.n_valid;
 
-    int k = 0;
-    for (int pass = 0; pass < n_pass; ++pass) {
-        // query fragments of this pass's groups: lane (j, g) holds Q[j][16 s + 4 g .. +3]
-        f32x4 qf[G][16];
+    int k = 0;                                                 // position in the tile sequence
+    for (int sg = 0; sg < n_sg; ++sg) {
+        // the lists of a supergroup's 4 query groups live in registers through its passes and
+        // are merged once, at its end: no merge work at a pass boundary
+        ShortList<L> lists[TOPKS_SG];
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            const int grp = min(pass * G + gi, a.n_groups - 1);
-            const int64_t q = (int64_t)grp * 16 + j;
-            const f32x4* rowp = reinterpret_cast<const f32x4*>(a.ehat + (q < a.B ? q : a.B - 1) * KEY_DIM);
+        for (int gi = 0; gi < TOPKS_SG; ++gi) lists[gi].init();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) qf[gi][s] = rowp[4 * s + g];
-        }
-        // (ordinary loads that hipcc counts: "using" them here puts its wait for them in front of
-        // the tile loop - at their first use inside it, it would be a vmcnt(0) that drains the
-        // hand-counted LDS-DMA ring every iteration)
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(qf[gi][s]));
-        }
-        ShortList<L> lists[G];
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) lists[gi].init();
-        // values of the previous tile, pushed while the current tile's MFMAs run (the first
-        // round pushes -inf: a no-op)
-        f32x4 prev[G];
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) prev[gi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        uint32_t prev_row0 = 0;
-        const uint32_t n_valid32 = (uint32_t)a.n_valid;
-        auto push_prev = [&](int gi) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t row = prev_row0 + prow[r];
-                // (pad rows exist in the bank's last tile only; the compare is cheaper than a branch)
-                const float x = row < n_valid32 ? prev[gi][r] : -INFINITY;
-                lists[gi].push(x, row);
-            }
-        };
-
-        for (int i = 0; i < T; ++i, ++k) {
-            const int tile = w_id + i * n_waves;
-            // tile k has landed when at most the 16 operations of tile k+1 are outstanding
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            const char* kt = my + (k & (DEPTH - 1)) * KT_BYTES;
-            f32x4 kf[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                kf[s] = *reinterpret_cast<const f32x4*>(kt + kaddr.b[s & 3] + 256 * (s >> 2));
-            // the slot is free once these reads have returned: refill it before the arithmetic
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(kf[s]));
-            issue_seq(k + 2);
-            if (tile < a.n_blocks) {
-                f32x4 acc[G];
+        for (int ps = 0; ps < PPS; ++ps) {
+            const int grp0 = (sg * PPS + ps) * G;                         // first group of this pass
+            if (grp0 < a.n_groups) {
+                // query fragments of this pass's groups: lane (j, g) holds Q[j][16 s + 4 g .. +3]
+                f32x4 qf[G][16];
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
-                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    const int grp = min(grp0 + gi, a.n_groups - 1);
+                    const int64_t q = (int64_t)grp * 16 + j;
+                    const f32x4* rowp =
+                        reinterpret_cast<const f32x4*>(a.ehat + (q < a.B ? q : a.B - 1) * KEY_DIM);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) qf[gi][s] = rowp[4 * s + g];
+                }
+                // (ordinary loads that hipcc counts: "using" them here puts its wait for them in
+                // front of the tile loop - at their first use inside it, it would be a vmcnt(0)
+                // that drains the hand-counted LDS-DMA ring every iteration)
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(qf[gi][s]));
+                }
+                // values of the previous tile, pushed while the current tile's MFMAs run (the
+                // first round pushes -inf: a no-op)
+                f32x4 prev[G];
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) prev[gi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                uint32_t prev_row0 = 0;
+                auto push_prev = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t row = prev_row0 + prow[r];
+                        // (pad rows exist in the bank's last tile only; a compare is cheaper than a branch)
+                        const float x = row < n_valid32 ? prev[gi][r] : -INFINITY;
+                        lists[ps * G + gi].push(x, row);
+                    }
+                };
+
+                for (int i = 0; i < T; ++i, ++k) {
+                    const int tile = w_id + i * n_waves;
+#ifndef RANGE_EXP_TS_NODMA
+                    // tile k has landed when at most the 16 operations of tile k+1 are outstanding
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
+                    if (k == 0) RANGE_TS_STAMP(2);            // first tile landed
+                    if (k == total - 1) RANGE_TS_STAMP(3);    // last tile landed
+                    const char* kt = my + (k & (DEPTH - 1)) * KT_BYTES;
+                    f32x4 kf[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        kf[s] = *reinterpret_cast<const f32x4*>(kt + kaddr.b[s & 3] + 256 * (s >> 2));
+                    // the slot is free once these reads have returned: refill it before the arithmetic
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(kf[s]));
+#ifndef RANGE_EXP_TS_NODMA   // timing experiment only (results invalid): no stream, compute only
+                    issue_seq(k + 2);
+#endif
+                    if (tile >= a.n_blocks) continue;      // (the ragged last round of a pass)
+                    f32x4 acc[G];
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) {
+                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #ifdef RANGE_EXP_TS_NOMFMA   // timing experiment only (results invalid)
-                    c = kf[gi] + kf[gi + 4] + qf[gi][3];
+                        c = kf[gi] + kf[gi + 4] + qf[gi][3];
 #else
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[gi][s].x, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[gi][s].y, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[gi][s].z, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[gi][s].w, c, 0, 0, 0);
-                    }
+                        for (int s = 0; s < 16; ++s) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[gi][s].x, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[gi][s].y, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[gi][s].z, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[gi][s].w, c, 0, 0, 0);
+                        }
 #endif
-                    acc[gi] = c;
-                    // list maintenance of the PREVIOUS tile's values of this group: independent of
-                    // the chain above, placed into its shadow (about 4 VALU instructions per MFMA)
+                        acc[gi] = c;
+                        // list maintenance of the PREVIOUS tile's values of this group:
+                        // independent of the chain above, placed into its shadow
 #ifdef RANGE_EXP_TS_NOPUSH   // timing experiment only (results invalid)
-                    lists[gi].v[0] += prev[gi][0] + prev[gi][1] + prev[gi][2] + prev[gi][3];
+                        lists[ps * G + gi].v[0] += prev[gi][0] + prev[gi][1] + prev[gi][2] + prev[gi][3];
 #else
-                    push_prev(gi);
+                        push_prev(gi);
 #endif
 #if RANGE_TOPKS_VALU_PER_MFMA > 0
 #pragma unroll
-                    for (int m = 0; m < 64; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x2, RANGE_TOPKS_VALU_PER_MFMA, 0);
-                    }
+                        for (int m = 0; m < 64; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x2, RANGE_TOPKS_VALU_PER_MFMA, 0);
+                        }
 #endif
+                    }
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) prev[gi] = acc[gi];
+                    prev_row0 = (uint32_t)tile * BLK;
                 }
 #pragma unroll
-                for (int gi = 0; gi < G; ++gi) prev[gi] = acc[gi];
-                prev_row0 = (uint32_t)tile * BLK;
+                for (int gi = 0; gi < G; ++gi) push_prev(gi);
             }
         }
+        RANGE_TS_STAMP(4);   // all tiles of the supergroup consumed
+        // end of the supergroup: per group, the 4 lanes of a query merge their lists (bitonic,
+        // shuffles only) and lane group 0 writes the wave's L best and its dmax.  No barrier,
+        // no LDS; the ring keeps streaming the next supergroup's first tiles meanwhile.
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) push_prev(gi);
-        // per group: merge the 4 lane lists of a query, then the 4 waves through LDS; one sorted
-        // list of 16 and one dmax per (group, workgroup, query) go to HBM.  The ring keeps
-        // streaming the next pass's first tiles meanwhile.
+        for (int gi = 0; gi < TOPKS_SG; ++gi) {
+            const int grp = sg * TOPKS_SG + gi;
+            if (grp < a.n_groups) {
+                unsigned long long kk[L];
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            const int grp = pass * G + gi;
-            KeyList Lk;
-            lists[gi].to_keys(Lk);
-            merge_lane_groups(Lk);
-            float dm = lists[gi].dmax;
-            dm = fmaxf(dm, __shfl_xor(dm, 16));
-            dm = fmaxf(dm, __shfl_xor(dm, 32));
-            if (g == 0) {
-#pragma unroll
-                for (int i = 0; i < MAX_TOPK; ++i) sh_keys[(wave * 16 + j) * MAX_TOPK + i] = Lk.k[i];
-                sh_dmax[wave * 16 + j] = dm;
-            }
-            __syncthreads();
-            if (wave == 0 && grp < a.n_groups) {
-                KeyList M;
-#pragma unroll
-                for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh_keys[(g * 16 + j) * MAX_TOPK + i];
-                merge_lane_groups(M);
-                float d4 = sh_dmax[g * 16 + j];
-                d4 = fmaxf(d4, __shfl_xor(d4, 16));
-                d4 = fmaxf(d4, __shfl_xor(d4, 32));
+                for (int i = 0; i < L; ++i)
+                    kk[i] = lists[gi].row[i] != 0xFFFFFFFFu ? topk_key(lists[gi].v[i], lists[gi].row[i]) : 0ull;
+                unsigned long long drop = 0ull;
+                merge4_short<L>(kk, drop);
+                float dm = lists[gi].dmax;
+                dm = fmaxf(dm, __shfl_xor(dm, 16));
+                dm = fmaxf(dm, __shfl_xor(dm, 32));
+                if (drop != 0ull) dm = fmaxf(dm, topk_key_val(drop));
                 if (g == 0) {
-                    const int64_t at = ((int64_t)grp * gridDim.x + blockIdx.x) * 16 + j;
-                    unsigned long long* o = a.cand + at * MAX_TOPK;
+                    const int64_t at = ((int64_t)grp * 16 + j) * n_waves + w_id;
+                    unsigned long long* o = a.cand + at * L;
 #pragma unroll
-                    for (int i = 0; i < MAX_TOPK; ++i) o[i] = M.k[i];
-                    a.dmax[at] = d4;
+                    for (int i = 0; i < L; i += 2)
+                        *reinterpret_cast<ulonglong2*>(o + i) = make_ulonglong2(kk[i], kk[i + 1]);
+                    a.dmax[at] = dm;
                 }
             }
-            __syncthreads();
         }
     }
+    RANGE_TS_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end
+    RANGE_TS_STAMP(6);
 }
 
-// One workgroup per query: thread p owns the sorted candidate list of stream workgroup p
-// (<= 512); every wave reduces its 64 lists, wave 0 the per-wave results.  Then the exactness
-// check of the short lists: if the largest value any lane let go reaches the k-th value found
-// (or `force_exact`), the query is recomputed by brute force over all rows, each thread walking
-// its rows with the SAME fmaf chain as the MFMA (k order: for s, for component, for lane group),
-// with full 16-deep lists.  exact_count (optional) counts the queries that took that path.
-__global__ __launch_bounds__(512) void topk_merge_kernel(const unsigned long long* cand, const float* dmax,
-                                                         int n_parts, int64_t B, int k, int64_t row_offset,
-                                                         const float* keys, const float* ehat, int64_t n_valid,
-                                                         int force_exact, int* exact_count,
-                                                         float* oval, int64_t* oidx) {
-    __shared__ unsigned long long sh[8 * MAX_TOPK];
-    __shared__ float sh_d[8];
+// One workgroup per query.  Thread p owns the sorted list (L keys) of stream wave p (<= 1024).
+//  1. a lower bound T of the query's 16th best value: inside each wave of this kernel, the 16th
+//     largest list head (rank by counting over the wave's 64 heads); T = the largest of the waves'
+//     bounds.  Entries below T cannot be in the top 16.
+//  2. the survivors (>= T; typically a few hundred of the 8192 entries) are compacted into LDS
+//     and ranked by counting; ranks 0..k-1 are the result, already in order (keys are unique).
+//  3. exactness of the short lists: if the largest value any lane or wave let go reaches the
+//     k-th value found (or the survivors overflow their buffer, or `force_exact`), the query is
+//     recomputed by brute force over all rows, each thread walking its rows with the SAME fmaf
+//     chain as the MFMA (k order: for s, for component, for lane group) and full 16-deep lists.
+//     exact_count (optional) counts the queries that took that path.
+constexpr int TOPKM_CAP = 2048;    // survivor buffer (keys)
+
+template <int L>
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long long* cand, const float* dmax,
+                                                          int n_parts, int64_t B, int k, int64_t row_offset,
+                                                          const float* keys, const float* ehat, int64_t n_valid,
+                                                          int force_exact, int* exact_count,
+                                                          float* oval, int64_t* oidx) {
+    __shared__ unsigned long long surv[TOPKM_CAP];
+    __shared__ unsigned long long sh[16 * MAX_TOPK];
+    __shared__ unsigned long long res[MAX_TOPK];
+    __shared__ uint32_t sh_t[16];
+    __shared__ float sh_d[16];
     __shared__ float sh_q[KEY_DIM];
-    __shared__ int sh_flag;
+    __shared__ int sh_cnt, sh_flag;
     const int n_wv = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = blockIdx.x;
     const int64_t group = q >> 4;
     const int p = threadIdx.x;
-    KeyList L;
-    L.init();
+    unsigned long long kk[L];
     float dm = -INFINITY;
-    if (p < n_parts) {
-        const int64_t at = (group * n_parts + p) * 16 + (q & 15);
-        const unsigned long long* src = cand + at * MAX_TOPK;
 #pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) L.k[i] = src[i];
+    for (int i = 0; i < L; ++i) kk[i] = 0ull;
+    if (p < n_parts) {
+        const int64_t at = (group * 16 + (q & 15)) * n_parts + p;   // contiguous over the threads
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(cand + at * L);
+#pragma unroll
+        for (int i = 0; i < L; i += 2) { const ulonglong2 t = src[i / 2]; kk[i] = t.x; kk[i + 1] = t.y; }
         dm = dmax[at];
     }
-    auto reduce = [&](KeyList& X) __attribute__((always_inline)) {   // result in wave 0, every lane
-        merge_wave(X);
-        if (lane == 0) {
+    if (threadIdx.x == 0) { sh_cnt = 0; sh_flag = 0; }
+    if (threadIdx.x < MAX_TOPK) res[threadIdx.x] = 0ull;
+    // ---- 1. lower bound of the 16th best value from the list heads (ordered value bits only)
+    const uint32_t head = (uint32_t)(kk[0] >> 32);       // 0 = empty list
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)head, i) > head ? 1 : 0;
+    uint32_t tw = (rank <= 15 && head != 0u) ? head : 0xFFFFFFFFu;    // min over the 16 best heads
 #pragma unroll
-            for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = X.k[i];
-        }
-        __syncthreads();
-        KeyList M;
-        M.init();
-        if (wave == 0) {
-            if (lane < n_wv) {
-#pragma unroll
-                for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
-            }
-            merge_wave(M);
-        }
-        __syncthreads();
-        return M;
-    };
-    KeyList M = reduce(L);
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_xor(tw, off); tw = o < tw ? o : tw; }
+    // (fewer than 16 non-empty heads in this wave: no bound from it)
+    const int n_heads = __popcll(__ballot(head != 0u));
+    if (lane == 0) sh_t[wave] = n_heads >= 16 ? tw : 0u;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) dm = fmaxf(dm, __shfl_xor(dm, off));
     if (lane == 0) sh_d[wave] = dm;
     __syncthreads();
+    uint32_t T = 0u;
+    float dall = -INFINITY;
+    for (int w = 0; w < n_wv; ++w) { T = sh_t[w] > T ? sh_t[w] : T; dall = fmaxf(dall, sh_d[w]); }
+    // ---- 2. survivors
+    // (one LDS atomic per wave and list position: the lanes of a wave take consecutive places)
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const bool keep = kk[i] != 0ull && (uint32_t)(kk[i] >> 32) >= T;
+        const unsigned long long m = __ballot(keep);
+        if (m != 0ull) {                                       // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && at < TOPKM_CAP) surv[at] = kk[i];
+        }
+    }
+    __syncthreads();
+    const int S = sh_cnt;
+    if (S <= TOPKM_CAP) {
+        for (int t = threadIdx.x; t < S; t += blockDim.x) {
+            const unsigned long long key = surv[t];
+            int r = 0;
+            for (int u = 0; u < S; ++u) r += surv[u] > key ? 1 : 0;
+            if (r < MAX_TOPK) res[r] = key;
+        }
+    }
+    __syncthreads();
+    // ---- 3. exactness
     if (threadIdx.x == 0) {
-        float d = sh_d[0];
-        for (int w = 1; w < n_wv; ++w) d = fmaxf(d, sh_d[w]);
-        // the k-th value found (nothing can have been dropped while fewer than k rows exist)
-        const unsigned long long kth = M.k[k - 1];
-        const bool unsafe = force_exact || (kth != 0ull && d >= topk_key_val(kth)) ||
-                            (kth == 0ull && d > -INFINITY);
+        const unsigned long long kth = res[k - 1];
+        // (nothing can have been dropped while fewer than k rows exist)
+        const bool unsafe = force_exact || S > TOPKM_CAP || (kth != 0ull && dall >= topk_key_val(kth)) ||
+                            (kth == 0ull && dall > -INFINITY);
         sh_flag = unsafe ? 1 : 0;
         if (unsafe && exact_count) atomicAdd(exact_count, 1);
     }
@@ -349,17 +432,31 @@ __global__ __launch_bounds__(512) void topk_merge_kernel(const unsigned long lon
             }
             X.push(topk_key(acc, (uint32_t)row));
         }
-        M = reduce(X);
-    }
-    if (threadIdx.x == 0) {
+        merge_wave(X);
+        if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < MAX_TOPK; ++i) {
-            if (i < k) {
-                const unsigned long long mm = M.k[i];
-                oval[q * k + i] = mm ? topk_key_val(mm) : -INFINITY;
-                oidx[q * k + i] = mm ? (int64_t)topk_key_row(mm) + row_offset : (int64_t)-1;
+            for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = X.k[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            KeyList M;
+            M.init();
+            if (lane < n_wv) {
+#pragma unroll
+                for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
+            }
+            merge_wave(M);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < MAX_TOPK; ++i) res[i] = M.k[i];
             }
         }
+        __syncthreads();
+    }
+    if (threadIdx.x < k) {
+        const unsigned long long mm = res[threadIdx.x];
+        oval[q * k + threadIdx.x] = mm ? topk_key_val(mm) : -INFINITY;
+        oidx[q * k + threadIdx.x] = mm ? (int64_t)topk_key_row(mm) + row_offset : (int64_t)-1;
     }
 }
 

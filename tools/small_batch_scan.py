@@ -33,11 +33,14 @@ for B, topk in (((16, 16), (32, 16), (64, 16)) if stream_only else
         torch.cuda.synchronize()
         ms, n = eng.profile_read(3)
         us = ms / n * 1e3
-        passes = (B + 15) // 16
+        mms, mn = eng.profile_read(4)
+        groups = (B + 15) // 16
+        G = int(os.environ.get('RANGE_TOPKS_GROUPS', '0')) or (1 if groups <= 1 else 2)
+        passes = (groups + G - 1) // G
         t0 = time.perf_counter()
         for _ in range(50): eng.topk_stream(e32, topk)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / 50 * 1e6
-        print(f"        B={B}: whole call {wall:6.1f} us;", end="")
+        print(f"        B={B}: whole call {wall:6.1f} us; merge kernel {mms / mn * 1e3:5.1f} us;", end="")
         print(f"        stream kernel: {us:8.1f} us  ({passes} key passes)  {passes*byt/us/1e6:6.2f} TB/s of keys = {100*passes*byt/us/1e6/8.0:5.1f} % of 8 TB/s")
         eng.profile_enable(False)
