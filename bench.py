@@ -136,7 +136,7 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     from range_amd import synth
     locs, vals, keys = bank_arrays
     obank = O.prep_bank(locs, vals, keys)
-    q = synth.make_queries(n_sample, seed=7)
+    q = synth.make_queries(n_sample, seed=7, lat_max=90.0)
 
     def run(qs, chunk):
         t_sh = t_si = t_re = 0.0
@@ -237,7 +237,10 @@ def main():
     bank_arrays = synth.make_bank(N, 2024)
     bank = prepare_bank(*bank_arrays)
     eng = _native.HipEngine(dev)
-    eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
+    # the product's default for an 'analytic' checkpoint: the reference's generated SH polynomials
+    from range_amd.range import sh_table_for
+    table = sh_table_for(enc)
+    eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases, sh_table=table)
     model = None
     if not sharded:
         eng.set_bank(bank.keys, bank.values, bank.xyz, 0)
@@ -264,7 +267,8 @@ def main():
         else:
             B = a.queries
         # the batch of the step: rank r owns queries [r*B, (r+1)*B) of ONE seeded batch
-        q_all = synth.make_queries(B * world, seed=7)
+        # (pole to pole: the result does not depend on latitude, the parity check below does)
+        q_all = synth.make_queries(B * world, seed=7, lat_max=90.0)
         q_host = q_all[rank * B:(rank + 1) * B]
         x = torch.from_numpy(q_host).to(dev)
         out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
@@ -312,13 +316,21 @@ def main():
         idx = np.linspace(0, B - 1, num=min(64, B), dtype=np.int64)
         qs = m["q_host"][idx]
         got = m["out"][torch.from_numpy(idx).to(dev)].cpu().numpy()
-        e = O.encode(qs, weights, L)
-        ref32 = O.retrieve(e, qs, obank, "RANGE+", a.beta)
-        ref64 = O.retrieve64(e, qs, obank, "RANGE+", a.beta)
+        # e-hat against the oracle fed with the same SH polynomials (CPU evaluation of the table;
+        # queries run pole to pole, where the reference's polynomials are ill-conditioned and the
+        # last bit of pow() shows: inside |lat| <= 45 the two agree to 1e-7), retrieval given e-hat
+        e = O.encode(qs, weights, L, features=table.evaluate(qs))
+        band = np.abs(qs[:, 1]) <= 45.0
+        got_e = got[:, 1024:]
+        ref32 = O.retrieve(got_e, qs, obank, "RANGE+", a.beta)
+        ref64 = O.retrieve64(got_e, qs, obank, "RANGE+", a.beta)
         parity = {"rows": int(idx.size),
                   "max_abs_vs_reference_f32_order": float(np.abs(got - ref32).max()),
                   "max_abs_vs_f64_oracle": float(np.abs(got[:, :1024] - ref64).max()),
-                  "ehat_max_abs": float(np.abs(got[:, 1024:] - e).max())}
+                  "ehat_max_abs_lat_le_45": float(np.abs(got_e - e)[band].max()),
+                  "ehat_max_abs_all_latitudes": float(np.abs(got_e - e).max())}
+        if not parity["ehat_max_abs_lat_le_45"] < 1e-6:
+            raise SystemExit(f"bench parity failed: {parity}")
         if not parity["max_abs_vs_reference_f32_order"] < 1e-4:
             raise SystemExit(f"bench parity failed: {parity}")
 
@@ -479,25 +491,34 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
 
 
 def host_contract_rate(eng, synth, torch, dev, beta, B):
-    """The reference's own contract: ``model(x)`` returns a FRESH host ndarray (B,1280) float64
-    (range/range.py:240).  Timed as the caller's loop of synchronous calls; never ``value``."""
+    """The reference's own contract: ``model(x)`` returns a host ndarray (B,1280) float64
+    (range/range.py:240).  Timed as the caller's loop of synchronous calls, once dropping each
+    result before the next call (its memory is recycled, range_amd/_hostpool.py) and once keeping
+    every result alive (each call fills fresh pages); ``value`` is the slower.  Never ``value`` of
+    the bench line."""
     from range_amd import _native
-    if not hasattr(eng, "forward_host"):
-        return None
     xs = [torch.from_numpy(synth.make_queries(B, seed=100 + i)).to(dev) for i in range(4)]
     eng.forward_host(xs[0], _native.MODEL_RANGE_PLUS, beta)
+    eng.forward_host(xs[1], _native.MODEL_RANGE_PLUS, beta)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    n = 0
-    keep = []
-    for rep in range(2):
-        for x in xs:
-            keep.append(eng.forward_host(x, _native.MODEL_RANGE_PLUS, beta))   # results stay alive
-            n += x.shape[0]
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "geo-embeddings/sec", "ms_per_batch": dt / (2 * len(xs)) * 1e3,
-            "what": f"{2 * len(xs)} synchronous calls of {B} queries, each returning a fresh "
-                    "host ndarray (B,1280) float64; inputs resident in HBM"}
+    res = {}
+    for mode in ("results_dropped", "results_kept"):
+        keep = []
+        t0 = time.perf_counter()
+        n = 0
+        for rep in range(2):
+            for x in xs:
+                r = eng.forward_host(x, _native.MODEL_RANGE_PLUS, beta)
+                if mode == "results_kept":
+                    keep.append(r)
+                n += x.shape[0]
+        dt = time.perf_counter() - t0
+        res[mode] = {"value": n / dt, "ms_per_batch": dt / (2 * len(xs)) * 1e3}
+        del keep
+    worst = min(res, key=lambda k: res[k]["value"])
+    return {"value": res[worst]["value"], "unit": "geo-embeddings/sec", **res,
+            "what": f"{2 * len(xs)} synchronous calls of {B} queries, each returning a host ndarray "
+                    "(B,1280) float64; inputs resident in HBM"}
 
 
 if __name__ == "__main__":

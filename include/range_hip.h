@@ -79,6 +79,20 @@ void range_destroy(range_ctx* ctx);
 int range_set_encoder(range_ctx* ctx, const range_encoder_desc* desc,
                       const double* const* weights, const double* const* biases);
 
+/* Reference-faithful "analytic" spherical harmonics.  range_set_encoder evaluates the basis by a
+ * stable recurrence (the exact-math value).  The reference evaluates machine-generated, fully
+ * expanded polynomials in cos(theta) whose coefficients (up to 1e14) are printed with 15 digits
+ * (satclip/positional_encoding/spherical_harmonics_generate_ylms.py:19-40; used at
+ * spherical_harmonics.py:35-42): towards the poles they cancel to values that differ from the
+ * exact ones by up to 0.5, deterministically.  With this table (range_amd/sh_table.py: parsed from
+ * the generated file or generated from scratch) the kernel walks the same sums in the same order.
+ * Arrays are indexed l*L+m (0 <= m <= l < L); terms off[i] .. off[i]+cnt[i]-1 of coef/pow:
+ *   Y_l^m = front * (a0 + a2 x^2)^(p2/2) * x^kx * sum_j coef_j x^pow_j * cos|sin(m phi), x = cos(theta).
+ * Call after range_set_encoder (which clears a previous table); analytic sh_mode only. */
+int range_set_sh_table(range_ctx* ctx, int32_t L, const double* front, const double* a0,
+                       const double* a2, const int32_t* p2, const int32_t* kx, const int32_t* off,
+                       const int32_t* cnt, int64_t n_terms, const double* coef, const int32_t* pow);
+
 /* Replaces the bank upload of range/range.py:98-100 (and the per-forward re-upload of the values
  * at :217/:236).  Inputs are HOST arrays already prepared exactly as range/range.py:78-95 does:
  * keys (n_rows x 256) float32 rows L2-normalised in float32; values (n_rows x 1024) float32;
@@ -222,7 +236,7 @@ int range_forward(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t m
  * returns when out_host is complete (it is synchronous, like the reference's `.cpu()`): finalize
  * runs per slab of 1024 queries, each slab's device->host DMA (pinned staging, a copy stream of
  * the context) overlaps the next slab's, and a few host threads (RANGE_HOST_THREADS, default
- * min(16, cores)) move landed slabs into out_host so that its first-touch page faults are spread
+ * min(8, cores)) move landed slabs into out_host so that its first-touch page faults are spread
  * over cores. */
 int range_forward_host(range_ctx* ctx, const double* lonlat_dev, int64_t B, int32_t model,
                        float beta, double* out_host, range_stream_t stream);

@@ -124,10 +124,12 @@ def siren_forward(y: np.ndarray, weights: Dict[str, np.ndarray], w0_initial: flo
 
 
 def encode(lonlat: np.ndarray, weights: Dict[str, np.ndarray], L: int,
-           mode: str = "analytic") -> np.ndarray:
+           mode: str = "analytic", features: Optional[np.ndarray] = None) -> np.ndarray:
     """Location encoder: SH features -> SirenNet (location_encoder.py:273-275), then the L2
-    normalisation of range/range.py:212.  Returns e-hat (B, 256) float64."""
-    e = siren_forward(sh_features(lonlat, L, mode), weights)
+    normalisation of range/range.py:212.  Returns e-hat (B, 256) float64.  ``features``: SH
+    features computed elsewhere (e.g. the reference's expanded polynomials evaluated from their
+    coefficient table) instead of the exact basis of ``sh_features``."""
+    e = siren_forward(sh_features(lonlat, L, mode) if features is None else features, weights)
     t = torch.from_numpy(e)
     return (t / t.norm(p=2, dim=-1, keepdim=True)).numpy()
 

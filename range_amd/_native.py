@@ -29,6 +29,7 @@ COORD_DIMS = {COORD_DIRECT: 2, COORD_CARTESIAN3D: 3, COORD_WRAP: 4}
 # every symbol include/range_hip.h declares
 SYMBOLS = (
     "range_abi_version", "range_last_error", "range_build_flags", "range_create", "range_destroy", "range_set_encoder",
+    "range_set_sh_table",
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
     "range_last_attend_geometry", "range_profile_enable", "range_profile_read",
@@ -69,6 +70,7 @@ def load_library() -> C.CDLL:
     lib.range_destroy.argtypes = [vp]
     lib.range_destroy.restype = None
     lib.range_set_encoder.argtypes = [vp, C.POINTER(EncoderDesc), C.POINTER(vp), C.POINTER(vp)]
+    lib.range_set_sh_table.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.range_set_bank.argtypes = [vp, vp, vp, vp, i64, i64]
     lib.range_bank_rows.argtypes = [vp]
     lib.range_bank_rows.restype = i64
@@ -150,7 +152,9 @@ class HipEngine:
     # -- setup ---------------------------------------------------------------------------------
     def set_encoder(self, L: int, hidden: int, num_hidden_layers: int, embed_dim: int,
                     sh_mode: int, weights: Sequence[np.ndarray],
-                    biases: Sequence[np.ndarray]) -> None:
+                    biases: Sequence[np.ndarray], sh_table=None) -> None:
+        """``sh_table`` (range_amd.sh_table.SHTable, analytic mode only): evaluate the spherical
+        harmonics through the reference's generated polynomials instead of the exact recurrence."""
         n = num_hidden_layers + 1
         if len(weights) != n or len(biases) != n:
             raise ValueError("need num_hidden_layers+1 weight and bias arrays")
@@ -166,6 +170,17 @@ class HipEngine:
         wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
         bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
         _check(self.lib, self.lib.range_set_encoder(self._h, C.byref(desc), wp, bp))
+        if sh_table is not None:
+            t = sh_table
+            f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)   # noqa: E731
+            i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)     # noqa: E731
+            arrs = [f64(t.front), f64(t.a0), f64(t.a2), i32(t.p2), i32(t.kx), i32(t.off), i32(t.cnt)]
+            coef, powr = f64(t.coef), i32(t.pow)
+            if any(a.shape != (L * L,) for a in arrs) or coef.shape != powr.shape:
+                raise ValueError("spherical-harmonics table does not match L")
+            _check(self.lib, self.lib.range_set_sh_table(
+                self._h, L, *[a.ctypes.data for a in arrs], coef.shape[0], coef.ctypes.data,
+                powr.ctypes.data))
 
     def set_bank(self, keys: np.ndarray, values: np.ndarray, xyz: np.ndarray,
                  row_offset: int = 0) -> None:
@@ -358,13 +373,15 @@ class HipEngine:
     def forward_host(self, lonlat: torch.Tensor, model: int, beta: float,
                      out: Optional[np.ndarray] = None) -> np.ndarray:
         """The reference's contract (range/range.py:240): the (B,1280) float64 result as a host
-        ndarray - a fresh one unless ``out`` (C-contiguous rows of a float64 array) is given.
+        ndarray - a new one (see ``_hostpool``) unless ``out`` (C-contiguous rows of a float64
+        array) is given.
         Synchronous; the device->host copy and the fill of the array are pipelined per slab
         inside the library (range_forward_host)."""
         self._t(lonlat, torch.float64, (2,))
         B = lonlat.shape[0]
         if out is None:
-            out = np.empty((B, OUT_DIM), dtype=np.float64)
+            from ._hostpool import POOL
+            out = POOL.take(B, OUT_DIM)     # memory of results the caller has dropped, else fresh
         elif out.shape != (B, OUT_DIM) or out.dtype != np.float64 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float64 array (B,1280)")
         _check(self.lib, self.lib.range_forward_host(self._h, lonlat.data_ptr(), B, model, beta,

@@ -34,6 +34,16 @@ constexpr int ENC_MAX_LAYERS = 8;      // hidden layers + last
 constexpr int ENC_SLOTS_PER_ROUND = 4;
 constexpr int ENC_EMBED = 256;
 
+// One entry per (l, m >= 0) of the reference's generated "analytic" functions (range_amd/sh_table.py):
+//   Y = front * (a0 + a2 x^2)^(p2/2) * x^kx * sum_j coef[off + j] * x^pow[off + j],  x = cos(theta)
+struct SHDesc {
+    double front, a0, a2;
+    int32_t off;
+    int16_t cnt;
+    int8_t p2, kx;
+};
+static_assert(sizeof(SHDesc) == 32, "SHDesc layout");
+
 struct EncArgs {
     const double* lonlat;   // (B,2)
     double* ehat64;         // (B,256) normalised
@@ -53,6 +63,11 @@ struct EncArgs {
     const double* coefA;        // [L*L] at l*L+m : a(l,m)            (0 for l<=m)
     const double* coefB;        // [L*L] at l*L+m : a(l,m)*b(l,m)
     const double* seedc;        // [L]  chain seed constant incl. convention factors
+    // reference-faithful analytic SH (null: stable recurrence): the generated polynomials'
+    // 15-digit coefficients, walked in the reference's operation order
+    const SHDesc* sh_desc;      // [L*L] at l*L+m
+    const double* sh_coef;
+    const int32_t* sh_pow;
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -188,7 +203,11 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const double DEG = 3.14159265358979323846 / 180.0;
 
     // ---- SH generator state: thread = (query gq, slot-in-round gslot); threads 128..255 idle
-    const int gq = tid & 31, gslot = tid >> 5;
+    //      (reference-faithful mode: every thread generates - thread = (query, slot, sub), the
+    //      polynomials of an order are dealt to the NSUB sub-threads by degree)
+    constexpr int NSUB = NW * 64 / (ENC_QTILE * ENC_SLOTS_PER_ROUND);
+    const int gq = tid & 31, gslot = a.sh_desc ? (tid >> 5) & (ENC_SLOTS_PER_ROUND - 1) : tid >> 5;
+    const int gsub = tid >> 7;
     double cx = 0, sx = 0, phi = 0;
     if (gslot < ENC_SLOTS_PER_ROUND) {
         const int64_t q = (q0 + gq < a.B) ? q0 + gq : a.B - 1;
@@ -205,6 +224,25 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         for (int qt = 0; qt < QT; ++qt) acc[qt][i] = f64x4{0, 0, 0, 0};
 
     const int L = a.L;
+    // Reference-faithful mode: the powers cos^k(theta), k < L, of this workgroup's queries, each the
+    // CORRECTLY ROUNDED float64 of the true power (double-double running product) - what the
+    // reference's torch.pow delivers up to its last bit.  The sums below cancel by up to 1e14, so
+    // they see every bit of their terms; the powers are shared through LDS ([32 queries][L]).
+    double* pwt = red + 16 * ENC_QTILE;
+    if (a.sh_desc && tid < ENC_QTILE) {
+        double hi = 1.0, lo = 0.0;
+        pwt[gq * L] = 1.0;
+        for (int k = 1; k < L; ++k) {
+            const double p = hi * cx;
+            double e = fma(hi, cx, -p);
+            e = fma(lo, cx, e);
+            const double h2 = p + e;
+            lo = e - (h2 - p);
+            hi = h2;
+            pwt[gq * L + k] = hi;
+        }
+    }
+    // (made visible to the other generator threads by the barrier that opens the first round)
     for (int rnd_i = 0; rnd_i < a.n_rounds; ++rnd_i) {
         // rounds are visited in a per-workgroup rotated order (same reason as kp_rot)
         const int rnd = (int)((rnd_i + blockIdx.x) % (unsigned)a.n_rounds);
@@ -214,7 +252,68 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         const int kp1 = a.slot_base[s_last];
         __syncthreads();   // previous round's fragment reads are done
         const int slot = s_first + gslot;
-        if (gslot < ENC_SLOTS_PER_ROUND && slot < s_last) {
+        if (a.sh_desc) {
+            // the generated functions Yl{l}_m{m} of this slot's orders, in the reference's order of
+            // operations: every product and every sum rounded on its own (no fused multiply-add),
+            // the terms of a sum left to right; degrees l = m + gsub, m + gsub + NSUB, ...
+            if (slot < s_last) {
+                const int pos0 = a.slot_base[slot] - kp0;
+                const int end = a.slot_base[slot + 1] - kp0;
+                const int m_a = slot;
+                const int m_b = (slot > 0 && L - slot > slot) ? L - slot : -1;
+                const double* pw = pwt + gq * L;
+                const double x2 = __dmul_rn(cx, cx);
+                int pos_m = pos0;
+                for (int c = 0; c < 2; ++c) {
+                    const int m = c == 0 ? m_a : m_b;
+                    if (m < 0) break;
+                    double cm = 1.0, sm = 0.0;
+                    if (m > 0) { cm = cos(m * phi); sm = sin(m * phi); }
+                    double f_a0 = 0.0, f_a2 = 0.0, f_sp = 1.0;     // the (a0 + a2 x^2)^(p2/2) factor:
+                    int f_p2 = 0;                                  // the same for nearly all l of an order
+                    for (int l = m + gsub; l < L; l += NSUB) {
+                        const SHDesc d = a.sh_desc[l * L + m];
+                        double v = d.front;
+                        if (d.p2) {
+                            if (d.p2 != f_p2 || d.a0 != f_a0 || d.a2 != f_a2) {
+                                f_p2 = d.p2; f_a0 = d.a0; f_a2 = d.a2;
+                                const double s2 = __dadd_rn(d.a0, __dmul_rn(d.a2, x2));
+                                double r = (d.p2 & 1) ? sqrt(s2) : 1.0;
+                                for (int i = 0; i < (d.p2 >> 1); ++i) r *= s2;
+                                f_sp = r;
+                            }
+                            v *= f_sp;
+                        }
+                        if (d.cnt) {
+                            const double* cf = a.sh_coef + d.off;
+                            const int32_t* pk = a.sh_pow + d.off;
+                            double sum = __dmul_rn(cf[0], pw[pk[0]]);
+                            int t = 1;
+                            for (; t + 4 <= d.cnt; t += 4) {      // loads of 4 terms in flight
+                                const double c0 = cf[t], c1 = cf[t + 1], c2 = cf[t + 2], c3 = cf[t + 3];
+                                const double p0 = pw[pk[t]], p1 = pw[pk[t + 1]], p2 = pw[pk[t + 2]], p3 = pw[pk[t + 3]];
+                                sum = __dadd_rn(sum, __dmul_rn(c0, p0));
+                                sum = __dadd_rn(sum, __dmul_rn(c1, p1));
+                                sum = __dadd_rn(sum, __dmul_rn(c2, p2));
+                                sum = __dadd_rn(sum, __dmul_rn(c3, p3));
+                            }
+                            for (; t < d.cnt; ++t) sum = __dadd_rn(sum, __dmul_rn(cf[t], pw[pk[t]]));
+                            v *= sum;
+                        }
+                        if (d.kx) v *= pw[d.kx];
+                        if (m == 0) {
+                            lds[act_addr(gq, pos_m + (l - m))] = v;
+                        } else {
+                            lds[act_addr(gq, pos_m + 2 * (l - m))] = v * cm;
+                            lds[act_addr(gq, pos_m + 2 * (l - m) + 1)] = v * sm;
+                        }
+                    }
+                    pos_m += (m == 0 ? 1 : 2) * (L - m);
+                }
+                if (gsub == 0)
+                    for (int pos = pos_m; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
+            }
+        } else if (gslot < ENC_SLOTS_PER_ROUND && slot < s_last) {
             int pos = a.slot_base[slot] - kp0;
             const int end = a.slot_base[slot + 1] - kp0;
             const int m_a = slot;

@@ -53,6 +53,10 @@ struct range_ctx {
     DevBuf<int32_t> d_slot_base;
     DevBuf<double> d_coefA, d_coefB, d_seedc;
     DevBuf<double> d_wp[ENC_MAX_LAYERS], d_bias[ENC_MAX_LAYERS];
+    DevBuf<SHDesc> d_sh_desc;
+    DevBuf<double> d_sh_coef;
+    DevBuf<int32_t> d_sh_pow;
+    size_t enc_lds_base = 0;     // LDS of the encoder without the power table of the faithful SH mode
     // bank
     bool has_bank = false;
     int64_t n_rows = 0, n_pad = 0, row_offset = 0;
@@ -405,9 +409,43 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     a.coefB = c->d_coefB.p;
     a.seedc = c->d_seedc.p;
     for (int i = 0; i <= NL; ++i) { a.wp[i] = c->d_wp[i].p; a.bias[i] = c->d_bias[i].p; }
-    c->enc_lds_bytes = lds_bytes;
+    c->enc_lds_bytes = c->enc_lds_base = lds_bytes;
     c->desc = *d;
     c->has_encoder = true;
+    return RANGE_OK;
+}
+
+int range_set_sh_table(range_ctx* c, int32_t L, const double* front, const double* a0, const double* a2,
+                       const int32_t* p2, const int32_t* kx, const int32_t* off, const int32_t* cnt,
+                       int64_t n_terms, const double* coef, const int32_t* pw) {
+    if (!c || !front || !a0 || !a2 || !p2 || !kx || !off || !cnt || (n_terms > 0 && (!coef || !pw)))
+        return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->has_encoder) return fail(RANGE_ERR_STATE, "encoder not set (range_set_encoder)");
+    if (c->desc.sh_mode != RANGE_SH_ANALYTIC)
+        return fail(RANGE_ERR_INVALID, "the coefficient table belongs to the 'analytic' spherical harmonics");
+    if (L != c->desc.legendre_polys) return fail(RANGE_ERR_INVALID, "table for L=%d, encoder has L=%d", L, c->desc.legendre_polys);
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    std::vector<SHDesc> desc((size_t)L * L);
+    for (int l = 0; l < L; ++l)
+        for (int m = 0; m <= l; ++m) {
+            const int i = l * L + m;
+            if (cnt[i] < 0 || off[i] < 0 || (int64_t)off[i] + cnt[i] > n_terms || p2[i] < 0 || p2[i] > 127 ||
+                kx[i] < 0 || kx[i] >= L || cnt[i] > 32767)
+                return fail(RANGE_ERR_INVALID, "bad table entry (l=%d, m=%d)", l, m);
+            desc[i] = SHDesc{front[i], a0[i], a2[i], off[i], (int16_t)cnt[i], (int8_t)p2[i], (int8_t)kx[i]};
+        }
+    for (int64_t j = 0; j < n_terms; ++j)
+        if (pw[j] < 0 || pw[j] >= L) return fail(RANGE_ERR_INVALID, "power %d out of range at term %lld", pw[j], (long long)j);
+    const size_t lds = c->enc_lds_base + (size_t)ENC_QTILE * L * sizeof(double);
+    if (lds > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS with the power table (>160 KiB)", lds);
+    HIP_TRY(c->d_sh_desc.upload(desc));
+    HIP_TRY(c->d_sh_coef.upload(std::vector<double>(coef, coef + std::max<int64_t>(n_terms, 1))));
+    HIP_TRY(c->d_sh_pow.upload(std::vector<int32_t>(pw, pw + std::max<int64_t>(n_terms, 1))));
+    c->enc.sh_desc = c->d_sh_desc.p;
+    c->enc.sh_coef = c->d_sh_coef.p;
+    c->enc.sh_pow = c->d_sh_pow.p;
+    c->enc_lds_bytes = lds;
     return RANGE_OK;
 }
 

@@ -17,6 +17,11 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
             it for every model name, also those that never read it.
         device: 'cuda' / 'cuda:N'.
         **kwargs: ``db_path`` (required) - the range_db_*.npz bank; ``beta`` (RANGE+, default 0.5).
+            Optional, not in the reference: ``sh_eval`` - 'reference' (default: 'analytic'
+            checkpoints evaluate the reference's own generated polynomials, so embeddings agree
+            with the reference at every latitude) or 'exact' (the mathematically exact basis);
+            ``sh_source`` - a generated ``spherical_harmonics_ylm.py`` to take the polynomial
+            coefficients from (default: regenerated, range_amd/sh_table.py).
     """
     if pretrained_path is None:
         raise ValueError("Please provide the pretrained model path.")      # load_model.py:31-32
@@ -29,6 +34,9 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
         beta = None
     args = Namespace(location_model_name=model_name, pretrained_path=pretrained_path,
                      device=device, range_db=db_path, beta=beta)           # :45-46
+    for opt in ("sh_eval", "sh_source"):
+        if opt in kwargs:
+            setattr(args, opt, kwargs[opt])
     model = LocationEncoder(args)
     model.eval()
     return model

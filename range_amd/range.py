@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _native
+from ._hostpool import POOL
 from .bank import PreparedBank
 from .bankfile import load_any as load_bank
 from .ckpt import EncoderParams, read_checkpoint
@@ -44,11 +45,42 @@ def _device_of(spec) -> torch.device:
     return dev
 
 
-def make_engine(enc: EncoderParams, bank: Optional[PreparedBank], device, row_offset: int = 0):
+_SH_TABLES = {}     # (L, source path or None) -> SHTable
+
+
+def sh_table_for(enc: EncoderParams, sh_eval: Optional[str] = None, sh_source: Optional[str] = None):
+    """The coefficient table of the reference's generated "analytic" spherical harmonics, or None.
+
+    ``sh_eval``: 'reference' (default for harmonics_calculation == 'analytic': the reference's own
+    expanded polynomials with their 15-digit coefficients, so that embeddings agree with the
+    reference at every latitude) or 'exact' (the stable recurrence: the mathematically exact basis,
+    which the reference itself only matches for |lat| <~ 45 deg).  'closed-form' checkpoints always
+    use the recurrence - it is what the reference runs for them
+    (spherical_harmonics_closed_form.py:8-40).  ``sh_source``: path of a generated
+    ``spherical_harmonics_ylm.py`` to take the coefficients from (default: regenerate them)."""
+    if sh_eval is None:
+        sh_eval = "reference"
+    if sh_eval not in ("reference", "exact"):
+        raise ValueError(f"sh_eval must be 'reference' or 'exact', got {sh_eval!r}")
+    if enc.harmonics_calculation != "analytic" or sh_eval == "exact":
+        return None
+    from . import sh_table
+    key = (enc.legendre_polys, sh_source)
+    if key not in _SH_TABLES:
+        if sh_source is not None:
+            with open(sh_source) as f:
+                _SH_TABLES[key] = sh_table.parse_ylm_source(f.read(), enc.legendre_polys)
+        else:
+            _SH_TABLES[key] = sh_table.generate_table(enc.legendre_polys)
+    return _SH_TABLES[key]
+
+
+def make_engine(enc: EncoderParams, bank: Optional[PreparedBank], device, row_offset: int = 0,
+                sh_eval: Optional[str] = None, sh_source: Optional[str] = None):
     eng = _native.HipEngine(device)
     mode = _native.SH_ANALYTIC if enc.harmonics_calculation == "analytic" else _native.SH_CLOSED_FORM
     eng.set_encoder(enc.legendre_polys, enc.hidden, enc.num_hidden_layers, enc.embed_dim, mode,
-                    enc.weights, enc.biases)
+                    enc.weights, enc.biases, sh_table=sh_table_for(enc, sh_eval, sh_source))
     if bank is not None:
         eng.set_bank(bank.keys, bank.values, bank.xyz, row_offset)
     return eng
@@ -88,7 +120,8 @@ class LocationEncoder(nn.Module):
             self.encoder_params = enc
             self.n_bank_rows = bank.n_rows
             self._device = _device_of(args.device)
-            self.engine = make_engine(enc, bank, self._device)
+            self.engine = make_engine(enc, bank, self._device, sh_eval=getattr(args, "sh_eval", None),
+                                      sh_source=getattr(args, "sh_source", None))
         elif self.location_model_name == "SatCLIP":                     # range.py:117-122
             print("Using SatCLIP")
             enc = read_checkpoint(args.pretrained_path)
@@ -98,7 +131,8 @@ class LocationEncoder(nn.Module):
             self._model_id = None
             self.encoder_params = enc
             self._device = _device_of(args.device)
-            self.engine = make_engine(enc, None, self._device)
+            self.engine = make_engine(enc, None, self._device, sh_eval=getattr(args, "sh_eval", None),
+                                      sh_source=getattr(args, "sh_source", None))
         elif self.location_model_name in _COORD_MODELS:                 # range.py:152-162, 170-173
             mode, banner = _COORD_MODELS[self.location_model_name]
             print(banner)
@@ -150,7 +184,7 @@ class LocationEncoder(nn.Module):
         if not return_device:
             # the reference's contract: a fresh host array (range.py:240), filled slab by slab
             # while the device->host copies of later slabs are in flight (range_forward_host)
-            host = np.empty((B, _native.OUT_DIM), dtype=np.float64)
+            host = POOL.take(B, _native.OUT_DIM)
             for i in range(0, B, self.chunk_size):
                 self.engine.forward_host(x[i:i + self.chunk_size], self._model_id, beta,
                                          out=host[i:i + self.chunk_size])

@@ -88,6 +88,65 @@ def test_encoder_vs_reference_golden(tag):
         assert d[lat <= 30].max() < 1e-7
 
 
+def test_encoder_over_all_latitudes():
+    """Pole to pole: the HIP encoder equals the exact-math oracle everywhere (2e-12); against the
+    reference's own numbers the tolerance is per latitude band (tests/test_oracle_golden.py:
+    LAT_BANDS) - the reference's expanded polynomials lose accuracy towards the poles."""
+    from test_oracle_golden import LAT_BANDS
+    z = np.load(os.path.join(GOLDEN, "latitude_L40_H512_n2.npz"))
+    q = z["lonlat"]
+    w, enc = _params(int(z["L"]), int(z["hidden"]), int(z["num_hidden_layers"]), int(z["seed"]), str(z["mode"]))
+    eng = _engine(enc)
+    e64 = eng.encode(_dev(q))[0].cpu().numpy()
+    np.testing.assert_allclose(e64, O.encode(q, w, int(z["L"]), str(z["mode"])), rtol=0, atol=2e-12)
+    d = np.abs(e64 - z["embedding"]).max(axis=1)
+    al = np.abs(q[:, 1])
+    for lo, hi, tol in LAT_BANDS:
+        m = (al >= lo) & (al < hi)
+        assert d[m].max() < tol, (lo, hi, d[m].max())
+
+
+def test_encoder_reference_mode_over_all_latitudes():
+    """sh_eval='reference' (the default of load_model for analytic checkpoints): the kernel walks
+    the reference's generated polynomials - 15-digit coefficients, the reference's order of
+    operations, correctly rounded powers.  Pole to pole it stays with the reference's own
+    embedding to within a few times the reference's OWN spread between two ways of calling it
+    (golden field self_spread), 30-100x closer than the exact basis is beyond 60 degrees."""
+    from range_amd import sh_table
+    from test_oracle_golden import LAT_BANDS
+    z = np.load(os.path.join(GOLDEN, "latitude_L40_H512_n2.npz"))
+    q = z["lonlat"]
+    L = int(z["L"])
+    w, enc = _params(L, int(z["hidden"]), int(z["num_hidden_layers"]), int(z["seed"]), str(z["mode"]))
+    table = sh_table.generate_table(L)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_encoder(L, enc.hidden, enc.num_hidden_layers, 256, _native.SH_ANALYTIC, enc.weights, enc.biases,
+                    sh_table=table)
+    e64, e32, xq = eng.encode(_dev(q))
+    e64 = e64.cpu().numpy()
+    assert np.abs(np.linalg.norm(e64, axis=1) - 1.0).max() < 1e-13
+    np.testing.assert_array_equal(e32.cpu().numpy(), e64.astype(np.float32))
+    d = np.abs(e64 - z["embedding"]).max(axis=1)
+    al = np.abs(q[:, 1])
+    # measured: 4e-11 / 3e-8 / 2e-6 / 8e-5 / 2e-4 (the exact basis: 8e-10 / 8e-7 / 2e-4 / 3e-3 / 6e-3)
+    for (lo, hi, _), tol in zip(LAT_BANDS, (1e-9, 5e-7, 3e-5, 6e-4, 1.5e-3)):
+        m = (al >= lo) & (al < hi)
+        assert d[m].max() < tol, (lo, hi, d[m].max())
+    assert d.max() < 1.5e-3          # ... and the north-star 1e-4 holds on |lat| <= 60 now
+    assert d[al <= 60].max() < 1e-4
+    # the same numbers from the CPU evaluation of the table (numpy pow instead of correctly
+    # rounded powers: agreement to the same few bits of pow)
+    ref = O.encode(q, w, L, features=table.evaluate(q))
+    assert np.abs(e64 - ref)[al <= 45].max() < 1e-7 and np.abs(e64 - ref).max() < 1.5e-3
+    # a table parsed from generated text gives the same engine state as the generated table
+    eng.set_encoder(L, enc.hidden, enc.num_hidden_layers, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
+    ex = eng.encode(_dev(q))[0].cpu().numpy()          # no table: back to the exact recurrence
+    np.testing.assert_allclose(ex, O.encode(q, w, L), rtol=0, atol=2e-12)
+    with pytest.raises(_native.RangeNativeError):      # closed-form checkpoints have no such table
+        eng.set_encoder(L, enc.hidden, enc.num_hidden_layers, 256, _native.SH_CLOSED_FORM, enc.weights,
+                        enc.biases, sh_table=table)
+
+
 # ----------------------------------------------------------------------------------------------
 def _synthetic_case(N, B, bank_seed=77, q_seed=5, L=10, H=64):
     locs, vals, keys = synth.make_bank(N, bank_seed)

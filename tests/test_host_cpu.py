@@ -186,3 +186,32 @@ def test_checkpoint_with_uninstalled_helper_classes(tmp_path):
     enc = read_checkpoint(p)
     assert (enc.legendre_polys, enc.hidden, enc.embed_dim) == (10, 64, 256)
     assert np.array_equal(enc.weights[0], synth.make_encoder_weights(10, 64)["layers.0.weight"])
+
+
+def test_host_result_pool_recycles_only_unreferenced_memory():
+    """range_amd/_hostpool.py: the memory of a dropped result is handed out again, but never
+    while a view of that result is alive (it would be overwritten under the caller)."""
+    from range_amd._hostpool import HostResultPool
+    P = HostResultPool()
+    a = P.take(64, 1280)
+    assert a.dtype == np.float64 and a.shape == (64, 1280) and a.flags.c_contiguous and a.flags.writeable
+    addr = a.ctypes.data
+    del a
+    assert P._free_bytes == 64 * 1280 * 8
+    b = P.take(64, 1280)
+    assert b.ctypes.data == addr and P._free_bytes == 0        # recycled
+    b[:] = 3.0
+    v = b[2:4]                                                 # a view outlives the result
+    del b
+    assert P._free_bytes == 0                                  # not recycled ...
+    c = P.take(64, 1280)
+    c[:] = 5.0
+    assert (v == 3.0).all()                                    # ... so the view keeps its data
+    t = c.T
+    del c
+    assert P._free_bytes == 0
+    del t, v
+    # bounded: at most max_free_per_size arrays of one size are kept
+    arrs = [P.take(8, 1280) for _ in range(5)]
+    del arrs
+    assert P._free_bytes == P.max_free_per_size * 8 * 1280 * 8

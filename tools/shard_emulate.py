@@ -1,52 +1,78 @@
 #!/usr/bin/env python3
 """What one rank of an N-GPU row-sharded run computes per step, on ONE GPU and without any
-communication: its own 10 000 queries through the encoder, pass 1 and pass 2 for ALL N*10 000
-queries against its 100 000/N bank rows (in 4 chunks, as ShardedRange does), finalize of its own
-slice.  The time of this against the single-GPU step bounds the scaling efficiency from above.
-Usage: python tools/shard_emulate.py [N ...]"""
-import sys, os
+communication, for both scaling modes of bench.py:
+
+  weak   : its own 10 000 queries through the encoder, pass 1 and pass 2 for ALL N*10 000 queries
+           against its 100 000/N bank rows (in the chunks ShardedRange uses), finalize of its slice
+  strong : BASELINE's 10 000-query batch in total: its own 10 000/N queries through the encoder,
+           pass 1 and pass 2 for all 10 000 queries against its 100 000/N rows, finalize of its slice
+
+The time of this against the single-GPU step bounds the scaling efficiency from above (the
+exchange - all-gather of 1 040 B per query, all-reduce of 8 B per query, all-to-all of 4 KB per
+query - comes on top; DESIGN.md section 6 prices it).
+Usage: python tools/shard_emulate.py [--json] [N ...]"""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
+
 from range_amd import _native, synth
 from range_amd.bank import prepare_bank
 
 dev = torch.device("cuda:0")
 w = synth.make_encoder_weights(40, 512, 256, 2, 1234)
 full = prepare_bank(*synth.make_bank(100000, 2024))
-B = 10000
-for W in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
-    n = 100000 // W
-    eng = _native.HipEngine(dev)
-    eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
-                    [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
-    eng.set_bank(full.keys[:n], full.values[:n], full.xyz[:n])
-    x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
-    e64, e32, xq = eng.encode(x)
-    e32_all, xq_all = e32.repeat(W, 1).contiguous(), xq.repeat(W, 1).contiguous()
-    cuts = [0] + [((B * c) // 4 + 32) // 64 * 64 for c in (1, 2, 3)] + [B]
+as_json = "--json" in sys.argv
+worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
+base = {}
+for mode in ("strong", "weak"):
+    for W in worlds:
+        n = 100000 // W
+        B = 10000 // W if mode == "strong" else 10000          # this rank's own queries
+        eng = _native.HipEngine(dev)
+        eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
+                        [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
+        eng.set_bank(full.keys[:n], full.values[:n], full.xyz[:n])
+        x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
+        e64, e32, xq = eng.encode(x)
+        e32_all, xq_all = e32.repeat(W, 1).contiguous(), xq.repeat(W, 1).contiguous()
+        # ShardedRange._chunk_bounds: 4 chunks when a rank's batch is large enough, else 1
+        n_chunks = max(1, min(4, B // 2048)) if W > 1 else 1
+        cuts = [0] + [((B * c) // n_chunks + 32) // 64 * 64 for c in range(1, n_chunks)] + [B]
 
-    def step():
-        eng.encode(x)
-        st = eng.scan_stats(e32_all, xq_all, 12.0, 40.0, keep_logits=True)
-        st = eng.merge_stats(st[None])
-        outs = []
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            first, m = W * lo, W * (hi - lo)
-            part = eng.attend_kept(first, xq_all[first:first + m], 12.0, 40.0, 0.5, st[first:first + m])
-            outs.append(eng.finalize(part.reshape(W, hi - lo, 1024), e64[lo:hi].contiguous()))
-        return outs
+        def step():
+            eng.encode(x)
+            st = eng.scan_stats(e32_all, xq_all, 12.0, 40.0, keep_logits=True)
+            outs = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                first, m = W * lo, W * (hi - lo)
+                part = eng.attend_kept(first, xq_all[first:first + m], 12.0, 40.0, 0.5, st[first:first + m])
+                outs.append(eng.finalize(part.reshape(W, hi - lo, 1024), e64[lo:hi].contiguous()))
+            return outs
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    eng.profile_enable(True)
-    a.record()
-    for _ in range(5):
-        step()
-    b.record(); b.synchronize()
-    ms = a.elapsed_time(b) / 5
-    k = {nm: round(eng.profile_read(i)[0] / 5, 3) for i, nm in enumerate(["encoder", "scan_stats", "attend"])}
-    qt, ns = eng.last_geometry()
-    print(f"N={W}: {ms:7.3f} ms per step and rank  kernels {k}  last pass-2 grid {qt} x {ns}", flush=True)
-    del eng
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng.profile_enable(True)
+        a.record()
+        for _ in range(5):
+            step()
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b) / 5
+        k = {nm: round(eng.profile_read(i)[0] / 5, 3) for i, nm in enumerate(["encoder", "scan_stats", "attend"])}
+        qt, ns = eng.last_geometry()
+        if W == 1:
+            base[mode] = ms
+        total_q = B * W
+        rec = {"mode": mode, "n_gpus": W, "ms_per_step_and_rank": round(ms, 3), "kernels_ms": k,
+               "queries_total": total_q, "compute_only_geo_embeddings_per_s": round(total_q / ms * 1e3),
+               "compute_only_speedup_vs_1": round((total_q / ms) / (10000 / base.get(mode, ms)), 3),
+               "chunks": n_chunks, "last_pass2_grid": [qt, ns]}
+        print(json.dumps(rec) if as_json else
+              f"{mode:6s} N={W}: {ms:7.3f} ms per step and rank  kernels {k}  grid {qt} x {ns}  "
+              f"compute-only speed-up x{rec['compute_only_speedup_vs_1']}", flush=True)
+        del eng
