@@ -91,10 +91,10 @@ class LocationEncoder(nn.Module):
 
     #: queries per engine call; bounds the per-call workspace (split slabs of chunk x 4 KB)
     chunk_size = 16384
-    #: topk(): batches up to this size use the HBM-streaming kernel (about 23 us per 16 queries on
-    #: range_db_large), larger ones pass 1 + a selection over its kept logits (about 0.16 ms up to
-    #: 128 queries, 0.55 ms at 1024; tools/topk_total_time.py)
-    topk_stream_max = 96
+    #: topk(): batches up to this size use the HBM-streaming kernel (about 25 us per 32 queries on
+    #: range_db_large: 108 us for 128 queries), larger ones pass 1 + a selection over its kept
+    #: logits (0.15 ms up to 128 queries, 0.19 ms at 256, 0.56 ms at 1024; tools/topk_total_time.py)
+    topk_stream_max = 160
 
     def __init__(self, args):
         super().__init__()
