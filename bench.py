@@ -341,6 +341,32 @@ def main():
         weak = {"value": mw["B"] * world * a.steps / mw["dt"], "ms_per_step": mw["dt"] / a.steps * 1e3,
                 "queries_per_gpu": mw["B"], "comm_ms_exposed_per_step":
                     None if mw["comm_ms"] is None else mw["comm_ms"] / a.steps}
+    control = None
+    if world > 1 and sharded and a.scaling == "strong" and not a.no_extras:
+        # the control experiment of SURVEY.md 8(e): the same batch with the whole bank on every GPU,
+        # each rank embedding its own queries end to end - no collective on the data path.  What the
+        # row-sharded figure loses against it is the price of the exchange (and of scanning all
+        # queries on every rank).
+        engc = _native.HipEngine(dev)
+        engc.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases, sh_table=table)
+        engc.set_bank(bank.keys, bank.values, bank.xyz, 0)
+        Bc = a.queries // world
+        xc = torch.from_numpy(synth.make_queries(Bc * world, seed=7, lat_max=90.0)[rank * Bc:(rank + 1) * Bc]).to(dev)
+        outc = torch.empty((Bc, 1280), dtype=torch.float64, device=dev)
+        for _ in range(max(1, a.warmup)):
+            engc.forward(xc, _native.MODEL_RANGE_PLUS, a.beta, out=outc)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            engc.forward(xc, _native.MODEL_RANGE_PLUS, a.beta, out=outc)
+        fence()
+        tc = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        # same queries, same bank: the two layouts must agree (split-order rounding only)
+        agree = float((outc - m["out"]).abs().max())
+        control = {"layout": "bank replicated, query-sharded, no collective", "value": Bc * world * a.steps / float(tc.item()),
+                   "ms_per_step": float(tc.item()) / a.steps * 1e3, "max_abs_vs_row_sharded": agree}
+        engc.close()
     scan = None
     host_contract = None
     if world == 1 and not sharded and not a.no_extras:
@@ -426,6 +452,8 @@ def main():
                                None if m["comm_ms"] is None else m["comm_ms"] / a.steps}
         if weak is not None:
             res["weak"] = weak
+        if control is not None:
+            res["control_query_sharded"] = control
         if scan is not None:
             res["roofline_scan"] = scan
         if host_contract is not None:

@@ -146,6 +146,7 @@ def test_bench_self_launches_two_ranks():
     assert r["dist"]["backend"] == "gloo" and r["dist"]["world_size"] == 2
     assert r["parity_max_abs"] < 1e-4
     assert r["weak"]["queries_per_gpu"] == 10_000
+    assert r["control_query_sharded"]["max_abs_vs_row_sharded"] < 1e-5     # two layouts, one answer
     # a rank that fails makes the launcher exit non-zero
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
                         "--warmup", "0", "--queries", "10001"],
