@@ -68,6 +68,11 @@ struct EncArgs {
     const SHDesc* sh_desc;      // [L*L] at l*L+m
     const double* sh_coef;
     const int32_t* sh_pow;
+    // small batches: the first layer split over n_parts workgroups per 16-query tile (each takes
+    // part_cols hidden columns and writes its activated slice to h1), the rest in a second kernel
+    double* h1;                 // (ceil(B/16)*16, H) f64
+    int32_t n_parts;
+    int32_t part_cols;
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -190,11 +195,16 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
 // QT = 16-query tiles of the workgroup: 2 (32 queries) or 1.  Workgroups are equal-cost, so a
 // batch that needs 1.2 rounds of 32-query workgroups pays for 2; the host then gives the LAST
 // round half-size workgroups (EncArgs::n_wg32), which finish in about half the time.
-template <int NT, int NW, int QT>
-__device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem) {
+// MODE 0: the whole encoder in one workgroup.  Small batches leave most CUs idle and every
+// workgroup streams all 9.5 MB of weights on its own (0.28 ms, whatever the batch): they run
+// MODE 1 - the first layer for ONE column part of a 16-query tile (NT = the part's width / 64,
+// `part` = which), activated slice written to a.h1 - on n_parts times as many workgroups, then
+// MODE 2 - everything after the first layer, from a.h1 - per tile.
+template <int NT, int NW, int QT, int MODE = 0>
+__device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem, int part = 0) {
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
-    static_assert(NTW * NW == 4 * NT && EW * NW == 16, "n-tiles must divide among the waves");
+    static_assert(NTW * NW == 4 * NT && (MODE == 1 || EW * NW == 16), "n-tiles must divide among the waves");
     double* lds = reinterpret_cast<double*>(smem);
     double* red = lds + a.lds_main_doubles;      // [NW waves][32 queries]
 
@@ -209,7 +219,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const int gq = tid & 31, gslot = a.sh_desc ? (tid >> 5) & (ENC_SLOTS_PER_ROUND - 1) : tid >> 5;
     const int gsub = tid >> 7;
     double cx = 0, sx = 0, phi = 0;
-    if (gslot < ENC_SLOTS_PER_ROUND) {
+    if (MODE != 2 && gslot < ENC_SLOTS_PER_ROUND) {
         const int64_t q = (q0 + gq < a.B) ? q0 + gq : a.B - 1;
         phi = (a.lonlat[2 * q] + 180.0) * DEG;                    // spherical_harmonics.py:31
         const double theta = (a.lonlat[2 * q + 1] + 90.0) * DEG;  // :32
@@ -229,7 +239,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     // reference's torch.pow delivers up to its last bit.  The sums below cancel by up to 1e14, so
     // they see every bit of their terms; the powers are shared through LDS ([32 queries][L]).
     double* pwt = red + 16 * ENC_QTILE;
-    if (a.sh_desc && tid < ENC_QTILE) {
+    if (MODE != 2 && a.sh_desc && tid < ENC_QTILE) {
         double hi = 1.0, lo = 0.0;
         pwt[gq * L] = 1.0;
         for (int k = 1; k < L; ++k) {
@@ -243,7 +253,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         }
     }
     // (made visible to the other generator threads by the barrier that opens the first round)
-    for (int rnd_i = 0; rnd_i < a.n_rounds; ++rnd_i) {
+    for (int rnd_i = 0; MODE != 2 && rnd_i < a.n_rounds; ++rnd_i) {
         // rounds are visited in a per-workgroup rotated order (same reason as kp_rot)
         const int rnd = (int)((rnd_i + blockIdx.x) % (unsigned)a.n_rounds);
         const int s_first = rnd * ENC_SLOTS_PER_ROUND;
@@ -343,8 +353,30 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         }
         __syncthreads();
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
-                          ((int64_t)(wave * NTW) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
+                          ((int64_t)((MODE == 1 ? part * (a.part_cols >> 4) : 0) + wave * NTW) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
         gemm_kpairs<NTW, QT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
+    }
+
+    if (MODE == 1) {
+        // the part's slice of h1 = sin(30 * (acc + b)) (location_encoder.py:119, 147-150) to HBM
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int n = part * a.part_cols + (wave * NTW + i) * 16 + (lane & 15);
+            const double bn = a.bias[0][n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t q = q0 + (lane >> 4) + 4 * r;      // (rows past B are scratch rows of h1)
+                a.h1[q * a.H + n] = sin(30.0 * (acc[0][i][r] + bn));
+            }
+        }
+        return;
+    }
+    if (MODE == 2) {
+        // the activated first layer of this tile, written by the MODE 1 workgroups
+        for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
+            const int q = idx / a.H, k = idx - q * a.H;
+            lds[act_addr(q, k)] = a.h1[(q0 + q) * a.H + k];
+        }
     }
 
     // ---- hidden layers: h = sin(w0 * (acc + b)), w0 = 30 on the first layer only
@@ -352,7 +384,8 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const int kpH = a.H >> 3;
     for (int layer = 0; layer < a.n_layers; ++layer) {
         __syncthreads();   // all waves finished reading the previous operand
-        store_act<NTW, QT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
+        if (!(MODE == 2 && layer == 0))
+            store_act<NTW, QT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
         __syncthreads();
         if (layer + 1 < a.n_layers) {
 #pragma unroll
@@ -434,6 +467,22 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         float4 o = make_float4((float)(cl * cos(lon)), (float)(cl * sin(lon)), (float)sin(lat), 0.f);
         *reinterpret_cast<float4*>(a.xq + q * 4) = o;
     }
+}
+
+// small-batch pair: first layer per (16-query tile, column part), then the rest per tile
+// (NWP waves: 8 where the part has at least 8 n-tiles - more threads for the feature generation,
+// which every part of a tile repeats)
+template <int NTP, int NWP>
+__global__ __launch_bounds__(NWP * 64, 1) void encoder_l1_part_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x / a.n_parts, part = blockIdx.x - tile * a.n_parts;
+    encoder_body<NTP, NWP, 1, 1>(a, (int64_t)tile * 16, smem, part);
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void encoder_rest_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    encoder_body<NT, NW, 1, 2>(a, (int64_t)blockIdx.x * 16, smem);
 }
 
 template <int NT, int NW>

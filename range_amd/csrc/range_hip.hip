@@ -69,13 +69,14 @@ struct range_ctx {
     int64_t kept_B = 0;
     int32_t kept_blocks = 0;
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
+    bool enc_split = true;    // RANGE_ENC_SPLIT=0: small batches use the one-kernel encoder too
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<float> ws_cand_dmax;
     DevBuf<int32_t> ws_exact_count;   // queries range_topk_stream recomputed by brute force
     int topks_groups = RANGE_TOPKS_GROUPS;   // RANGE_TOPKS_GROUPS in the environment overrides
     bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
-    DevBuf<double> ws_ehat64;
+    DevBuf<double> ws_ehat64, ws_h1;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
@@ -149,8 +150,66 @@ int set_dyn_lds(K kernel, size_t bytes) {
     return RANGE_OK;
 }
 
+// Small batches (fewer 16-query tiles than half the CUs): the first layer - 70 % of the weights
+// a workgroup streams - is split over S column parts per tile on S times as many workgroups
+// (encoder_l1_part_kernel), the rest follows per tile (encoder_rest_kernel).  One workgroup's
+// serial chain over all weights takes 0.28 ms whatever the batch; this pair takes about half.
+int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
+    const int tiles = (int)((a.B + 15) / 16);
+    if (c->ws_h1.ensure((size_t)tiles * 16 * a.H) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
+    a.h1 = c->ws_h1.p;
+    a.n_parts = S;
+    a.part_cols = a.H / S;
+    a.n_wg32 = 0;
+    const size_t lds = c->enc_lds_bytes;
+    const int ntp = a.part_cols / 64;
+    int rc = RANGE_OK;
+    ProfScope ps(c, RANGE_PROF_ENCODER, s);
+#define RANGE_ENC_PART(NTP, NWP)                                                               \
+    case NTP:                                                                                  \
+        rc = set_dyn_lds(encoder_l1_part_kernel<NTP, NWP>, lds);                               \
+        if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL((encoder_l1_part_kernel<NTP, NWP>), dim3(tiles * S), dim3(NWP * 64), lds, s, a); \
+        break;
+    switch (ntp) {
+        RANGE_ENC_PART(1, 4)
+        RANGE_ENC_PART(2, 8)
+        RANGE_ENC_PART(4, 8)
+        default: return fail(RANGE_ERR_INVALID, "internal: encoder part width %d", a.part_cols);
+    }
+#undef RANGE_ENC_PART
+    HIP_TRY(hipGetLastError());
+#define RANGE_ENC_REST(NT, NW)                                                                 \
+    case NT:                                                                                   \
+        rc = set_dyn_lds(encoder_rest_kernel<NT, NW>, lds);                                    \
+        if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL((encoder_rest_kernel<NT, NW>), dim3(tiles), dim3(NW * 64), lds, s, a); \
+        break;
+    switch (a.H / 64) {
+        RANGE_ENC_REST(2, 4)
+        RANGE_ENC_REST(4, RANGE_ENC_WAVES)
+        RANGE_ENC_REST(6, 4)
+        RANGE_ENC_REST(8, RANGE_ENC_WAVES)
+        default: return fail(RANGE_ERR_INVALID, "internal: hidden width %d", a.H);
+    }
+#undef RANGE_ENC_REST
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
 int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     EncArgs a = a_in;
+    {
+        // parts per tile: a power of two that divides H/64, keeps every part >= 64 columns and
+        // gives every workgroup its own CU
+        const int64_t tiles = (a.B + 15) / 16;
+        int S = 1;
+        for (int s2 = 2; s2 <= 8 && tiles * s2 <= c->n_cu; s2 *= 2) {
+            const int part = a.H / s2;
+            if (a.H % s2 == 0 && (part == 64 || part == 128 || part == 256)) S = s2;   // parts a kernel exists for
+        }
+        if (S > 1 && c->enc_split) return launch_encoder_split(c, a, S, s);
+    }
     // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
     // them would be less than half full, it is run with 16-query workgroups instead (about half
     // the time each): 10 000 queries = 256 x 32 + 113 x 16 instead of 313 x 32.
@@ -272,6 +331,7 @@ int range_create(int device, range_ctx** out) {
     const char* keep = std::getenv("RANGE_KEEP_LOGITS");
     c->allow_keep = !(keep && keep[0] == '0');
     if (const char* e = std::getenv("RANGE_HOST_TIMING")) c->host_timing = e[0] == '1';
+    if (const char* e = std::getenv("RANGE_ENC_SPLIT")) c->enc_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     *out = c;

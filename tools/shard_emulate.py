@@ -18,12 +18,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from range_amd import _native, synth
+from range_amd import _native, sh_table, synth
 from range_amd.bank import prepare_bank
 
 dev = torch.device("cuda:0")
 w = synth.make_encoder_weights(40, 512, 256, 2, 1234)
 full = prepare_bank(*synth.make_bank(100000, 2024))
+TABLE = sh_table.generate_table(40)      # load_model's default for an analytic checkpoint
 as_json = "--json" in sys.argv
 worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
 base = {}
@@ -33,7 +34,7 @@ for mode in ("strong", "weak"):
         B = 10000 // W if mode == "strong" else 10000          # this rank's own queries
         eng = _native.HipEngine(dev)
         eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
-                        [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
+                        [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]], sh_table=TABLE)
         eng.set_bank(full.keys[:n], full.values[:n], full.xyz[:n])
         x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
         e64, e32, xq = eng.encode(x)
