@@ -252,6 +252,15 @@ __device__ __forceinline__ void dma_b128_q(const void* sbase, uint32_t voff, int
         default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff), "s"(sbase) : "memory"); break;
     }
 }
+// the same with the non-temporal cache policy (streamed-once data: the key scan of a single pass)
+__device__ __forceinline__ void dma_b128_q_nt(const void* sbase, uint32_t voff, int q) {
+    switch (q) {
+        case 0: asm volatile("global_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(sbase) : "memory"); break;
+        case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024 nt" :: "v"(voff), "s"(sbase) : "memory"); break;
+        case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048 nt" :: "v"(voff), "s"(sbase) : "memory"); break;
+        default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072 nt" :: "v"(voff), "s"(sbase) : "memory"); break;
+    }
+}
 __device__ __forceinline__ void dma_b32(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2"
                  :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");

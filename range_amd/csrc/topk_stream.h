@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
             dma_group_begin(dst + gr * 4096);
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4)
-                dma_b128_q(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i4)) << 4), i4);
+                // (non-temporal: a key tile is read by exactly one wave per pass - measured 1 us
+                // per 16-query launch and 3 us per four passes faster than the default policy)
+                dma_b128_q_nt(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i4)) << 4), i4);
         }
     };
     issue_seq(0);

@@ -43,6 +43,27 @@ class EmbeddingPipeline:
             self._dev[slot] = torch.empty((n, dim), dtype=torch.float64, device=self.device)
         return self._pinned[slot][:n], self._dev[slot][:n]
 
+    def _coords_async(self, slot: int, coords) -> torch.Tensor:
+        """Host coordinates go to the device through a pinned staging buffer with a non-blocking
+        copy on the compute stream.  (A plain ``.to(device)`` of pageable memory blocks the host
+        until EVERYTHING queued on the device has finished - the previous batch and its 2 ms
+        device->host copy - so the next batch was enqueued late and the GPU idled 2-3 ms per batch.)"""
+        if torch.is_tensor(coords) and coords.is_cuda:
+            return self.model._coords(coords)
+        c = coords if torch.is_tensor(coords) else torch.as_tensor(np.asarray(coords))
+        if c.dim() != 2 or c.shape[1] != 2:
+            raise ValueError(f"coords must be (B,2) (lon,lat) degrees, got {tuple(c.shape)}")
+        n = c.shape[0]
+        st = self.model.__dict__.setdefault("_pipeline_coords", {})
+        key = (self.depth, slot)
+        if key not in st or st[key][0].shape[0] < n:
+            st[key] = (torch.empty((n, 2), dtype=torch.float64).pin_memory(),
+                       torch.empty((n, 2), dtype=torch.float64, device=self.device))
+        hp, dv = st[key]
+        hp[:n].copy_(c)                       # (also widens float32 input)
+        dv[:n].copy_(hp[:n], non_blocking=True)
+        return dv[:n]
+
     @torch.no_grad()
     def run(self, batches: Iterable) -> Iterator[np.ndarray]:
         """``batches`` yields (B,2) coordinate tensors/arrays.  Yields one float64 ndarray
@@ -61,7 +82,7 @@ class EmbeddingPipeline:
             slot = i % self.depth
             if len(inflight) == self.depth:           # slot about to be reused: drain it first
                 yield self._collect(*inflight.pop(0))
-            x = self.model._coords(coords)
+            x = self._coords_async(slot, coords)
             n = x.shape[0]
             pinned, dev = self._buffers(slot, n)
             beta = 1.0 if self.model._model_id == 0 else float(self.model.args.beta)
