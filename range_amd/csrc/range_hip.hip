@@ -16,6 +16,7 @@
 #include "../../include/range_hip.h"
 #include "host_common.h"
 #include "host_copy.h"
+#include "host_plan.h"
 #include "attend_kernels.h"
 #include "topk_stream.h"
 #include "encoder_kernel.h"
@@ -69,6 +70,7 @@ struct range_ctx {
     int64_t kept_B = 0;
     int32_t kept_blocks = 0;
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
+    bool warned_no_keep = false;
     bool enc_split = true;    // RANGE_ENC_SPLIT=0: small batches use the one-kernel encoder too
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
@@ -117,31 +119,6 @@ struct ProfScope {
 }  // namespace
 
 namespace {
-
-// Number of bank splits.  Workgroups of both scan kernels are equal-cost, so the chip runs them
-// in near lock-step "rounds" of n_cu * wg_per_cu workgroups: pick the split count whose last
-// round is best filled (e.g. 157 query tiles x 13 splits = 2041 workgroups = 7.97 rounds of 256),
-// preferring fewer splits (less partial-result traffic) on near-ties.  wg_per_cu: 1 for pass 2
-// (512 registers, 129 KB LDS), 4 for pass 1 (33 KB LDS, <= 128 VGPRs).
-int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, int max_splits,
-                  double split_cost = 0.002) {
-    const double slots = (double)n_cu * wg_per_cu;
-    const int cap = std::max(1, std::min(max_splits, n_blocks / 4));   // >= 4 blocks per split
-    // small batches: first of all give every slot a workgroup
-    const int ns_min = std::min(cap, (int)std::ceil(slots / n_qtiles));
-    int best = ns_min;
-    double best_score = -1e9;
-    for (int ns = ns_min; ns <= cap; ++ns) {
-        const double total = (double)n_qtiles * ns;
-        const double rounds = std::ceil(total / slots);
-        double score = total / (rounds * slots);            // fill of the rounds
-        if (rounds < 4) score *= 0.85 + 0.0375 * rounds;    // few rounds: ragged finish hurts more
-        score -= split_cost * (ns - ns_min);                // partial-result traffic
-        if (score > best_score) { best_score = score; best = ns; }
-        if (ns - ns_min > 64) break;
-    }
-    return best;
-}
 
 template <typename K>
 int set_dyn_lds(K kernel, size_t bytes) {
@@ -360,87 +337,20 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
 
-    // ---- slot plan: permuted + padded first-layer K order
-    // slot 0 = order 0; slot s>=1 = orders {s, L-s} (s < L-s) or {s} (s == L-s)
-    std::vector<int> slot_m_a, slot_m_b;
-    slot_m_a.push_back(0);
-    slot_m_b.push_back(-1);
-    for (int s = 1; s <= L - s && s < L; ++s) {
-        slot_m_a.push_back(s);
-        slot_m_b.push_back(L - s > s ? L - s : -1);
-    }
-    const int n_slots = (int)slot_m_a.size();
-    std::vector<int32_t> slot_base(n_slots + 1, 0);
-    std::vector<int> perm;   // padded position -> original feature index or -1
-    for (int s = 0; s < n_slots; ++s) {
-        slot_base[s] = (int32_t)perm.size();
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int m = c2 == 0 ? slot_m_a[s] : slot_m_b[s];
-            if (m < 0) break;
-            for (int l = m; l < L; ++l) {
-                if (m == 0) perm.push_back(l * l + l);
-                else { perm.push_back(l * l + l + m); perm.push_back(l * l + l - m); }
-            }
-        }
-        while (perm.size() % 8) perm.push_back(-1);   // whole k-step pairs (8 features)
-    }
-    slot_base[n_slots] = (int32_t)perm.size();
-    {   // every feature exactly once
-        std::vector<char> seen(L * L, 0);
-        int cnt = 0;
-        for (int p : perm) if (p >= 0) { if (seen[p]) return fail(RANGE_ERR_INVALID, "internal: perm duplicate"); seen[p] = 1; ++cnt; }
-        if (cnt != L * L) return fail(RANGE_ERR_INVALID, "internal: perm incomplete");
-    }
-    const int Kp = (int)perm.size();
-    const int n_rounds = (n_slots + ENC_SLOTS_PER_ROUND - 1) / ENC_SLOTS_PER_ROUND;
-    int max_round = 0;
-    for (int r = 0; r < n_rounds; ++r) {
-        const int s1 = std::min((r + 1) * ENC_SLOTS_PER_ROUND, n_slots);
-        max_round = std::max(max_round, slot_base[s1] - slot_base[r * ENC_SLOTS_PER_ROUND]);
-    }
-    const int lds_main = ENC_QTILE * std::max(max_round, H);
+    // ---- slot plan, recurrence tables, weight packing: pure host arithmetic (host_plan.h, also
+    //      built and run under sanitizers on the CPU: tests/native/host_sanitize.cpp)
+    EncoderPlan plan;
+    if (!build_encoder_plan(L, ENC_SLOTS_PER_ROUND, plan)) return fail(RANGE_ERR_INVALID, "internal: slot plan is not a permutation");
+    const std::vector<int>& perm = plan.perm;
+    const std::vector<int32_t>& slot_base = plan.slot_base;
+    const int n_slots = plan.n_slots, n_rounds = plan.n_rounds, Kp = (int)perm.size();
+    const int lds_main = ENC_QTILE * std::max(plan.max_round, H);
     const size_t lds_bytes = (size_t)(lds_main + 16 * ENC_QTILE) * sizeof(double);   // + [<= 16 waves][32] partial norms
     if (lds_bytes > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS (>160 KiB)", lds_bytes);
-
-    // ---- recurrence tables (float64)
-    std::vector<double> coefA((size_t)L * L, 0.0), coefB((size_t)L * L, 0.0), seedc(L, 0.0);
-    const double PI = 3.14159265358979323846;
-    double cm = std::sqrt(1.0 / (4.0 * PI));
-    for (int m = 0; m < L; ++m) {
-        if (m > 0) cm *= std::sqrt((2.0 * m + 1.0) / (2.0 * m));
-        double scale;
-        if (m == 0) scale = d->sh_mode == RANGE_SH_ANALYTIC ? PI : 1.0;
-        else scale = std::sqrt(2.0) * ((d->sh_mode == RANGE_SH_CLOSED_FORM && (m & 1)) ? -1.0 : 1.0);
-        seedc[m] = cm * scale;
-        for (int l = m + 1; l < L; ++l) {
-            if (l == m + 1) {
-                coefA[(size_t)l * L + m] = std::sqrt(2.0 * m + 3.0);
-                coefB[(size_t)l * L + m] = 0.0;
-            } else {
-                const double a = std::sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
-                const double b = std::sqrt((((double)l - 1.0) * (l - 1.0) - (double)m * m) /
-                                           (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
-                coefA[(size_t)l * L + m] = a;
-                coefB[(size_t)l * L + m] = a * b;
-            }
-        }
-    }
-
-    // ---- weights into MFMA B-fragment order, two k-steps per 16-byte lane element:
-    //      [((ntile*kpairs + kpair)*64 + lane)*2 + e] = W[ntile*16 + (lane&15)][kpair*8 + 4e + (lane>>4)]
+    std::vector<double> coefA, coefB, seedc;
+    recurrence_tables(L, d->sh_mode == RANGE_SH_ANALYTIC, coefA, coefB, seedc);
     auto pack = [](const double* W, int n_out, int k_in, const std::vector<int>* kperm, int Kpad) {
-        const int kp = Kpad / 8, nt = n_out / 16;
-        std::vector<double> out((size_t)nt * kp * 128);
-        for (int t = 0; t < nt; ++t)
-            for (int s = 0; s < kp; ++s)
-                for (int ln = 0; ln < 64; ++ln)
-                    for (int e = 0; e < 2; ++e) {
-                        const int n = t * 16 + (ln & 15);
-                        const int kk = s * 8 + 4 * e + (ln >> 4);
-                        const int k = kperm ? (*kperm)[kk] : kk;
-                        out[(((size_t)t * kp + s) * 64 + ln) * 2 + e] = k >= 0 ? W[(size_t)n * k_in + k] : 0.0;
-                    }
-        return out;
+        return pack_weights(W, n_out, k_in, kperm, Kpad);
     };
     for (int i = 0; i <= NL; ++i) if (!weights[i] || !biases[i]) return fail(RANGE_ERR_INVALID, "weights[%d]/biases[%d] null", i, i);
     HIP_TRY(c->d_wp[0].upload(pack(weights[0], H, L * L, &perm, Kp)));
@@ -652,10 +562,17 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
         if (need > c->ws_logits.n) {        // (hipMemGetInfo is slow: only when growing)
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            if (need * sizeof(float) <= free_b / 2)
+            if (need * sizeof(float) <= free_b / 2) {
                 HIP_TRY(c->ws_logits.ensure(need));
-            else
+            } else {
                 write_logits = false;
+                if (!c->warned_no_keep) {   // once per context: pass 2 will recompute the logits (25 % more MFMAs)
+                    c->warned_no_keep = true;
+                    std::fprintf(stderr, "librange_hip: the logits of %lld queries x %lld bank rows (%.1f GB) do not fit in "
+                                 "half of the free device memory (%.1f GB free): not kept, pass 2 recomputes them\n",
+                                 (long long)B, (long long)c->n_rows, need * 4e-9, free_b * 1e-9);
+                }
+            }
         }
     }
     const bool topk_from_kept = topk > 0 && write_logits;

@@ -1,0 +1,103 @@
+// Host-side code of librange_hip.so under sanitizers (CPU only; GPU sanitizers are not available
+// on the target pool).  Built by tests/test_host_cpu.py with
+//   g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-sanitize-recover=all   (run 1)
+//   g++ -std=c++17 -g -O1 -fsanitize=thread                                        (run 2)
+// from the very headers the library compiles: host_plan.h (launch geometry, encoder slot plan,
+// recurrence tables, weight packing) and host_copy.h (the thread pool that fills the caller's
+// host array).  Exits non-zero on a failed invariant; a sanitizer report aborts the process.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "../../range_amd/csrc/host_copy.h"
+#include "../../range_amd/csrc/host_plan.h"
+
+using namespace range_host;
+
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            std::exit(1);                                                        \
+        }                                                                        \
+    } while (0)
+
+static void test_plan_and_packing() {
+    std::mt19937_64 rng(7);
+    for (int L : {1, 2, 3, 7, 10, 16, 33, 40, 64}) {
+        EncoderPlan p;
+        CHECK(build_encoder_plan(L, 4, p));
+        CHECK((int)p.perm.size() % 8 == 0 && p.slot_base.front() == 0 && p.slot_base.back() == (int)p.perm.size());
+        std::vector<int> seen((size_t)L * L, 0);
+        for (int f : p.perm) if (f >= 0) { CHECK(f < L * L); ++seen[f]; }
+        for (int v : seen) CHECK(v == 1);
+        for (int s = 0; s < p.n_slots; ++s) CHECK(p.slot_base[s] % 8 == 0 && p.slot_base[s] < p.slot_base[s + 1]);
+        CHECK(p.max_round <= 8 * L + 8 * 4 && p.n_rounds * 4 >= p.n_slots);
+        std::vector<double> A, B, S;
+        recurrence_tables(L, true, A, B, S);
+        CHECK((int)A.size() == L * L && (int)S.size() == L);
+        for (double v : S) CHECK(std::isfinite(v) && v > 0.0);
+        recurrence_tables(L, false, A, B, S);
+        for (int m = 0; m < L; ++m) CHECK((S[m] < 0.0) == (m > 0 && (m & 1)));
+        // packing: every weight lands exactly once at the fragment position the kernel reads
+        for (int H : {64, 192, 512}) {
+            const int K = L * L, Kp = (int)p.perm.size();
+            std::vector<double> W((size_t)H * K);
+            for (auto& v : W) v = (double)(rng() % 1000003) + 1.0;
+            const std::vector<double> P = pack_weights(W.data(), H, K, &p.perm, Kp);
+            CHECK(P.size() == (size_t)H * Kp);
+            double sw = 0, sp = 0;
+            for (double v : W) sw += v;
+            for (double v : P) sp += v;
+            CHECK(sw == sp);
+            const int kp = Kp / 8;
+            for (int trial = 0; trial < 200; ++trial) {
+                const int n = (int)(rng() % H), kk = (int)(rng() % Kp);
+                const int t = n / 16, s = kk / 8, e = (kk % 8) / 4, ln = (n & 15) + 16 * (kk % 4);
+                const double got = P[(((size_t)t * kp + s) * 64 + ln) * 2 + e];
+                CHECK(got == (p.perm[kk] >= 0 ? W[(size_t)n * K + p.perm[kk]] : 0.0));
+            }
+        }
+    }
+}
+
+static void test_choose_splits() {
+    for (int qt : {1, 2, 16, 79, 157, 1563})
+        for (int nb : {1, 3, 4, 64, 782, 3125, 6250})
+            for (int per_cu : {1, 4})
+                for (int cap : {1, 16, 128, 2048}) {
+                    const int ns = choose_splits(qt, nb, 256, per_cu, cap, 0.002);
+                    CHECK(ns >= 1 && ns <= std::max(1, std::min(cap, nb / 4 > 0 ? nb / 4 : 1)));
+                }
+    CHECK(choose_splits(157, 6250, 256, 1, 32, 0.0014) == 13);   // the bench geometry
+}
+
+static void test_copy_pool() {
+    std::mt19937_64 rng(11);
+    for (int threads : {1, 3, 8}) {
+        HostCopyPool pool(threads);
+        for (size_t bytes : {(size_t)0, (size_t)1, (size_t)4095, (size_t)1 << 20, ((size_t)1 << 20) + 7,
+                             (size_t)10485760 + 13, (size_t)33 << 20}) {
+            std::vector<unsigned char> src(bytes + 64), dst(bytes + 64, 0xEE);
+            for (auto& v : src) v = (unsigned char)rng();
+            pool.copy(dst.data() + 32, src.data() + 17, bytes);          // unaligned on purpose
+            CHECK(std::memcmp(dst.data() + 32, src.data() + 17, bytes) == 0);
+            for (int i = 0; i < 32; ++i) CHECK(dst[i] == 0xEE && dst[32 + bytes + i] == 0xEE);   // nothing beyond
+        }
+        // jobs back to back reuse the workers
+        std::vector<int> hits(threads, 0);
+        for (int rep = 0; rep < 50; ++rep) pool.run([&](int t, int n) { CHECK(n == threads); ++hits[t]; });
+        for (int v : hits) CHECK(v == 50);
+    }
+}
+
+int main() {
+    test_plan_and_packing();
+    test_choose_splits();
+    test_copy_pool();
+    std::puts("host_sanitize ok");
+    return 0;
+}

@@ -215,3 +215,37 @@ def test_host_result_pool_recycles_only_unreferenced_memory():
     arrs = [P.take(8, 1280) for _ in range(5)]
     del arrs
     assert P._free_bytes == P.max_free_per_size * 8 * 1280 * 8
+
+
+@pytest.mark.parametrize("flags", [["-fsanitize=address,undefined", "-fno-sanitize-recover=all"],
+                                   ["-fsanitize=thread"]], ids=["asan+ubsan", "tsan"])
+def test_host_code_under_sanitizers(flags, tmp_path):
+    """The host-side arithmetic and threading of the C-ABI library (range_amd/csrc/host_plan.h,
+    host_copy.h - the headers librange_hip.so itself is built from) compiled with g++ under
+    sanitizers and run on the CPU (sanitizers on the CPU build only)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_sanitize")
+    src = os.path.join(REPO, "tests", "native", "host_sanitize.cpp")
+    subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-pthread", *flags, src, "-o", exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "host_sanitize ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_bench_self_launch_fails_loudly_without_gpus():
+    """``python bench.py --gpus 2`` from a plain shell spawns its rank processes (never touching
+    a GPU in the parent) and exits NON-ZERO when the ranks fail - here because there is no GPU."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU case")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=REPO)
+    assert p.returncode != 0
+    assert "needs an MI355X" in p.stderr + p.stdout
+    assert '{"metric"' not in p.stdout
