@@ -337,7 +337,7 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     __shared__ unsigned long long surv[TOPKM_CAP];
     __shared__ unsigned long long sh[16 * MAX_TOPK];
     __shared__ unsigned long long res[MAX_TOPK];
-    __shared__ uint32_t sh_t[16];
+    __shared__ uint32_t sh_top[64];
     __shared__ float sh_d[16];
     __shared__ float sh_q[KEY_DIM];
     __shared__ int sh_cnt, sh_flag;
@@ -359,24 +359,41 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     }
     if (threadIdx.x == 0) { sh_cnt = 0; sh_flag = 0; }
     if (threadIdx.x < MAX_TOPK) res[threadIdx.x] = 0ull;
-    // ---- 1. lower bound of the 16th best value from the list heads (ordered value bits only)
+    // ---- 1. lower bound T of the 16th best value (ordered value bits only): every wave hands in
+    //      its K largest list heads (n_wv * K >= 32 values, each the head of a different list, so
+    //      sixteen candidates are >= the 16th largest of them); with 1024 lists that is close to
+    //      the 20th-25th largest head overall and a few dozen entries survive it
     const uint32_t head = (uint32_t)(kk[0] >> 32);       // 0 = empty list
-    int rank = 0;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)head, i) > head ? 1 : 0;
-    uint32_t tw = (rank <= 15 && head != 0u) ? head : 0xFFFFFFFFu;    // min over the 16 best heads
+    const int K = max(2, (32 + n_wv - 1) / n_wv);        // n_wv * K in [32, 47]
+    {
+        uint32_t h = head;
+        for (int r = 0; r < K; ++r) {
+            uint32_t m = h;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_xor(tw, off); tw = o < tw ? o : tw; }
-    // (fewer than 16 non-empty heads in this wave: no bound from it)
-    const int n_heads = __popcll(__ballot(head != 0u));
-    if (lane == 0) sh_t[wave] = n_heads >= 16 ? tw : 0u;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
+            if (lane == 0) sh_top[wave * K + r] = m;
+            const unsigned long long holders = __ballot(h == m && m != 0u);
+            if (holders != 0ull && lane == __ffsll((long long)holders) - 1) h = 0u;   // one holder leaves
+        }
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) dm = fmaxf(dm, __shfl_xor(dm, off));
     if (lane == 0) sh_d[wave] = dm;
     __syncthreads();
     uint32_t T = 0u;
+    {
+        const int nv = n_wv * K;                         // <= 47
+        const uint32_t v = lane < nv ? sh_top[lane] : 0u;
+        int rank = 0;                                    // unique ranks: ties by lane
+        for (int i = 0; i < nv; ++i) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+            rank += (o > v || (o == v && i < lane)) ? 1 : 0;
+        }
+        const unsigned long long at15 = __ballot(lane < nv && rank == 15);
+        if (at15 != 0ull) T = (uint32_t)__builtin_amdgcn_readlane((int)v, __ffsll((long long)at15) - 1);
+    }
     float dall = -INFINITY;
-    for (int w = 0; w < n_wv; ++w) { T = sh_t[w] > T ? sh_t[w] : T; dall = fmaxf(dall, sh_d[w]); }
+    for (int w = 0; w < n_wv; ++w) dall = fmaxf(dall, sh_d[w]);
     // ---- 2. survivors
     // (one LDS atomic per wave and list position: the lanes of a wave take consecutive places)
 #pragma unroll
