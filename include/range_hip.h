@@ -12,7 +12,8 @@
  *   - every function returns RANGE_OK (0) or a negative error code; range_last_error() gives the
  *     message of the last failure on the calling thread.  Nothing throws across the ABI.
  *   - "dev" pointers are device memory owned by the caller (e.g. torch tensors' data_ptr());
- *     "host" pointers are ordinary host memory, only read during the call.
+ *     "host" pointers are ordinary host memory, read during the call (written by
+ *     range_forward_host / range_host_copy, whose result IS host memory).
  *   - a ctx is bound to one GPU, is not thread-safe, owns its bank copy and workspace
  *     (hipMalloc), and may be used from any stream; calls are asynchronous on `stream` except
  *     where stated.  Several ctxs (one per GPU / per process) may coexist.

@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2 -o p --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc3 -o p -- $B --steps 3 --warmup 1 > $O/p3.log 2>&1
 RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan1 -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan.log 2>&1
+RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan1_pmc -o p -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1_pmc.log 2>&1
 python3 $R/profiles/pmc_summarize.py $O/pmc1 $O/pmc2 $O/pmc3 > $O/pmc_summary.json
 cp $O/ks/ks_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 cut -c1-300 $O/bench_line.json
