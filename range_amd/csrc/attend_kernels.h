@@ -857,7 +857,13 @@ __device__ __forceinline__ void acc_fence(f32x4 (&acc)[64]) {
 
 // LDS map (bytes): V ring 3 x 32 KB | K ring 2 x 16 KB | X ring 2 x 256 B  = 131,584 B
 constexpr int ATTEND_LDS_BYTES = (3 * 8 * VAL_DIM + 2 * BLK * KEY_DIM + 2 * 64) * 4;
-constexpr int SCAN_LDS_BYTES = (2 * BLK * KEY_DIM + 2 * 64) * 4;
+// pass 1: workgroups per CU (4 = what the 33 KB of LDS allow; fewer by padding the allocation:
+// measured 3 and 2 per CU slower, tools/README.md)
+#ifndef RANGE_P1_WG_PER_CU
+#define RANGE_P1_WG_PER_CU 4
+#endif
+constexpr int SCAN_LDS_BYTES = RANGE_P1_WG_PER_CU >= 4 ? (2 * BLK * KEY_DIM + 2 * 64) * 4
+                                                       : (160 * 1024 / RANGE_P1_WG_PER_CU) / 256 * 256 - 512;
 
 template <bool GEO, bool DIAG = false>
 __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {

@@ -257,7 +257,7 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     // split of pass 2 writes and re-reads a 4 KB row per query: 8 KB at ~4 TB/s against the
     // query's MFMA time n_rows * 2054 FLOP / 140 TFLOP/s, i.e. 140 / n_rows of the launch - small
     // for the whole bank on one GPU, 1 % per split for a 12 500-row shard.
-    a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 4, p1_max_splits)
+    a.n_splits = pass1 ? choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, RANGE_P1_WG_PER_CU, p1_max_splits)
                        : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1,
                                        std::max(32, std::min(512, (c->n_cu + a.n_qtiles - 1) / a.n_qtiles)),
                                        std::max(0.001, 140.0 / (double)c->n_rows));
