@@ -666,11 +666,16 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     hipStream_t s = (hipStream_t)stream;
     const int n_groups = (int)((B + 15) / 16);
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
-    // persistent grid: one workgroup per CU (its rings fill the LDS), 4 waves each streaming
-    // their own tiles; one candidate list per (group, wave, query), merged by one thread each
+    // persistent grid: one workgroup per CU (its key tiles fill the LDS), 4 waves each streaming
+    // its own tiles; one candidate list per (group, wave, query).  Query groups sharing one pass
+    // over the keys: 2 groups (32 queries) are still at the ridge (16 FLOP per key byte) and take
+    // the time of 1.3.
     constexpr int LIST = RANGE_TOPKS_LIST;
-    const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + 3) / 4));
-    const int n_lists = n_wg * 4;
+    constexpr int NWV = 4, DEP = 2;
+    int G = c->topks_groups;
+    if (G != 1 && G != 2) G = n_groups <= 1 ? 1 : 2;
+    const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + NWV - 1) / NWV));
+    const int n_lists = n_wg * NWV;
     HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_lists * 16 * LIST));
     HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * n_lists * 16));
     if (!c->ws_exact_count.p) {
@@ -692,18 +697,14 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     HIP_TRY(hipMemsetAsync(stamps_buf.p, 0, (size_t)n_lists * 64, s));
     a.stamps = stamps_buf.p;
 #endif
-    // query groups sharing one pass over the keys: 2 groups (32 queries) are still HBM-bound (16
-    // FLOP per key byte against a ridge of ~20) and take the time of 1
-    int G = c->topks_groups;
-    if (G != 1 && G != 2) G = n_groups <= 1 ? 1 : 2;
     int rc = RANGE_OK;
 #define RANGE_TOPKS_LAUNCH(GG)                                                                      \
     do {                                                                                            \
-        rc = set_dyn_lds(topk_stream_kernel<GG, LIST>, TOPKS_LDS_BYTES);                            \
+        rc = set_dyn_lds(topk_stream_kernel<GG, LIST, NWV, DEP>, TOPKS_LDS_BYTES);                  \
         if (rc) return rc;                                                                          \
         ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);                                                 \
-        hipLaunchKernelGGL((topk_stream_kernel<GG, LIST>), dim3((unsigned)n_wg), dim3(256),         \
-                           TOPKS_LDS_BYTES, s, a);                                                  \
+        hipLaunchKernelGGL((topk_stream_kernel<GG, LIST, NWV, DEP>), dim3((unsigned)n_wg),          \
+                           dim3(NWV * 64), TOPKS_LDS_BYTES, s, a);                                  \
     } while (0)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (repeats > 1) {
@@ -735,29 +736,41 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         for (int w = 0; w < n_lists; ++w) t0 = std::min(t0, h[(size_t)w * 8]);
         std::fprintf(stderr, "topk_stream stamps (us: min med max)");
         for (int i = 0; i < 7; ++i) {
+            if (i == 3) continue;                          // (slot 3 holds a sum, printed below)
             std::vector<double> v;
             for (int w = 0; w < n_lists; ++w) v.push_back((double)(h[(size_t)w * 8 + i] - t0) * 0.01);
             std::sort(v.begin(), v.end());
             std::fprintf(stderr, " | %d: %.1f %.1f %.1f", i, v.front(), v[v.size() / 2], v.back());
         }
+        {   // loop sums (us): waiting for tiles / issuing LDS-DMA / arithmetic
+            std::vector<double> w, is, cp;
+            for (int x = 0; x < n_lists; ++x) {
+                w.push_back((double)h[(size_t)x * 8 + 3] * 0.01);
+                is.push_back((double)(h[(size_t)x * 8 + 7] >> 32) * 0.01);
+                cp.push_back((double)(h[(size_t)x * 8 + 7] & 0xFFFFFFFFull) * 0.01);
+            }
+            std::sort(w.begin(), w.end()); std::sort(is.begin(), is.end()); std::sort(cp.begin(), cp.end());
+            std::fprintf(stderr, "\n  per wave over the tile loop (us, min med max): waiting %.1f %.1f %.1f | issuing DMA %.1f %.1f %.1f | arithmetic %.1f %.1f %.1f",
+                         w.front(), w[w.size() / 2], w.back(), is.front(), is[is.size() / 2], is.back(), cp.front(), cp[cp.size() / 2], cp.back());
+        }
         std::fprintf(stderr, "\n  end of tiles (stamp 4) by blockIdx %% 8:");
         for (int x = 0; x < 8; ++x) {
             std::vector<double> v;
-            for (int w = 0; w < n_lists; ++w) if ((w / 4) % 8 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            for (int w = 0; w < n_lists; ++w) if ((w % n_wg) % 8 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
             std::sort(v.begin(), v.end());
             std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
         }
         std::fprintf(stderr, "\n  by blockIdx / 32:");
         for (int x = 0; x < (n_wg + 31) / 32; ++x) {
             std::vector<double> v;
-            for (int w = 0; w < n_lists; ++w) if ((w / 4) / 32 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            for (int w = 0; w < n_lists; ++w) if ((w % n_wg) / 32 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
             std::sort(v.begin(), v.end());
             std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
         }
         std::fprintf(stderr, "\n  by wave in workgroup:");
         for (int x = 0; x < 4; ++x) {
             std::vector<double> v;
-            for (int w = 0; w < n_lists; ++w) if (w % 4 == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
+            for (int w = 0; w < n_lists; ++w) if (w / n_wg == x) v.push_back((double)(h[(size_t)w * 8 + 4] - t0) * 0.01);
             std::sort(v.begin(), v.end());
             std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
         }

@@ -45,16 +45,19 @@ struct TopkStreamArgs {
 
 #ifdef RANGE_EXP_TS_STAMPS   // tuning only: where a wave's time goes (100 MHz real-time counter)
 #define RANGE_TS_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(size_t)w_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RANGE_TS_NOW() __builtin_amdgcn_s_memrealtime()
+#define RANGE_TS_ADD(acc, t0) (acc) += __builtin_amdgcn_s_memrealtime() - (t0)
 #else
 #define RANGE_TS_STAMP(i) do { } while (0)
+#define RANGE_TS_NOW() 0ull
+#define RANGE_TS_ADD(acc, t0) do { } while (0)
 #endif
 
 #ifndef RANGE_TOPKS_VALU_PER_MFMA
 #define RANGE_TOPKS_VALU_PER_MFMA 4
 #endif
-constexpr int TOPKS_DEPTH = 2;      // ring slots per wave
 constexpr int TOPKS_SG = 4;         // groups whose lists a wave carries through consecutive passes
-constexpr int TOPKS_LDS_BYTES = 4 * TOPKS_DEPTH * BLK * KEY_DIM * 4;
+constexpr int TOPKS_LDS_BYTES = 8 * BLK * KEY_DIM * 4;          // 128 KB of key tiles per workgroup
 
 // Sorted (descending) list of the L best (value, row) a lane has met, plus the largest value it
 // has let go.  push() is branch-free: the new value replaces the last entry if it is larger and
@@ -120,12 +123,20 @@ __device__ __forceinline__ void merge4_short(unsigned long long (&k)[L], unsigne
     }
 }
 
-template <int G, int L>
-__global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
+// NW waves per workgroup, each with a ring of DEPTH tiles (NW * DEPTH * 16 KB of LDS = 128 KB).
+// Per-wave stamps (RANGE_EXP_TS_STAMPS) show that with 4 waves x 2 tiles a wave never waits for a
+// tile once the first has landed: over a pass it spends 7.9 us in arithmetic, 2.4 us issuing
+// LDS-DMA and 0 us waiting.  8 waves x 1 tile (two waves per SIMD, K fragments to registers and the
+// slot refilled before the arithmetic) was measured for the 1-group kernel: 21.4 us instead of 21.6
+// at 16 queries, but 37.3 / 70 us instead of 36.2 / 63.6 at 2 / 4 passes (2048 waves leave 3.05
+// tiles per wave and pass: the last-tile imbalance grows) and a merge over twice the lists - so
+// every instantiation is 4 x 2.
+template <int G, int L, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64, NW / 4) void topk_stream_kernel(TopkStreamArgs a) {
     static_assert(TOPKS_SG % G == 0, "groups per pass must divide the supergroup");
+    static_assert(NW * DEPTH == 8 && (DEPTH == 1 || DEPTH == 2), "128 KB of key tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t KT_BYTES = BLK * KEY_DIM * 4;
-    constexpr int DEPTH = TOPKS_DEPTH;
     constexpr int PPS = TOPKS_SG / G;                          // passes per supergroup
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,11 +144,13 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * DEPTH * KT_BYTES;
     const char* my = smem + wave * DEPTH * KT_BYTES;
 
-    const int n_waves = gridDim.x * 4;
-    const int w_id = blockIdx.x * 4 + wave;
+    const int n_waves = gridDim.x * NW;
+    // (wave-major ids: the waves that get one tile more than the rest - the first n_blocks mod
+    // n_waves ids - are then spread one per CU instead of filling whole workgroups)
+    const int w_id = wave * gridDim.x + blockIdx.x;
     // this wave's tiles: w_id, w_id + n_waves, ... once per pass (T per pass, the last one of a
     // pass possibly past the bank: fetched as the bank's last tile, never consumed).  (Dealing a
-    // workgroup's tiles to its 4 waves through a counter in LDS was measured: the spread of the
+    // workgroup's tiles to its waves through a counter in LDS was measured: the spread of the
     // waves' finishing times is between XCDs and CUs, not inside a workgroup, and did not shrink.)
     const int T = (a.n_blocks + n_waves - 1) / n_waves;        // tiles per wave and pass
     const int n_pass = (a.n_groups + G - 1) / G;               // passes over the keys, all supergroups
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
         const int i = k < total ? k % T : T - 1;
         const int tile = w_id + i * n_waves;
         const float* src = a.keys + (int64_t)(tile < last ? tile : last) * BLK * KEY_DIM;
-        const uint32_t dst = lds0 + (k & (DEPTH - 1)) * KT_BYTES;
+        const uint32_t dst = lds0 + (k % DEPTH) * KT_BYTES;
 #pragma unroll
         for (int gr = 0; gr < 4; ++gr) {
             dma_group_begin(dst + gr * 4096);
@@ -164,8 +177,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
                 dma_b128_q_nt(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i4)) << 4), i4);
         }
     };
-    issue_seq(0);
-    issue_seq(1);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue_seq(d);
     RANGE_TS_STAMP(1);
 
     KAddr kaddr;
@@ -176,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
     const uint32_t n_valid32 = (uint32_t)a.n_valid;
 
     int k = 0;                                                 // position in the tile sequence
+    unsigned long long ts_wait = 0, ts_issue = 0, ts_comp = 0; // (stamp builds: time in each part of the loop)
     for (int sg = 0; sg < n_sg; ++sg) {
         // the lists of a supergroup's 4 query groups live in registers through its passes and
         // are merged once, at its end: no merge work at a pass boundary
@@ -223,13 +237,15 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
 
                 for (int i = 0; i < T; ++i, ++k) {
                     const int tile = w_id + i * n_waves;
+                    const unsigned long long ts0 = RANGE_TS_NOW();
 #ifndef RANGE_EXP_TS_NODMA
-                    // tile k has landed when at most the 16 operations of tile k+1 are outstanding
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    // tile k has landed when at most the 16 operations of each younger tile are outstanding
+                    if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+                    RANGE_TS_ADD(ts_wait, ts0);
                     if (k == 0) RANGE_TS_STAMP(2);            // first tile landed
-                    if (k == total - 1) RANGE_TS_STAMP(3);    // last tile landed
-                    const char* kt = my + (k & (DEPTH - 1)) * KT_BYTES;
+                    const char* kt = my + (k % DEPTH) * KT_BYTES;
                     f32x4 kf[16];
 #pragma unroll
                     for (int s = 0; s < 16; ++s)
@@ -238,10 +254,13 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(kf[s]));
+                    const unsigned long long ts1 = RANGE_TS_NOW();
 #ifndef RANGE_EXP_TS_NODMA   // timing experiment only (results invalid): no stream, compute only
-                    issue_seq(k + 2);
+                    issue_seq(k + DEPTH);
 #endif
+                    RANGE_TS_ADD(ts_issue, ts1);
                     if (tile >= a.n_blocks) continue;      // (the ragged last round of a pass)
+                    const unsigned long long ts2 = RANGE_TS_NOW();
                     f32x4 acc[G];
 #pragma unroll
                     for (int gi = 0; gi < G; ++gi) {
@@ -276,6 +295,10 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
 #pragma unroll
                     for (int gi = 0; gi < G; ++gi) prev[gi] = acc[gi];
                     prev_row0 = (uint32_t)tile * BLK;
+#ifdef RANGE_EXP_TS_STAMPS
+                    asm volatile("" :: "v"(prev[0]));      // (the tile's results are in registers here)
+#endif
+                    RANGE_TS_ADD(ts_comp, ts2);
                 }
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) push_prev(gi);
@@ -313,6 +336,12 @@ __global__ __launch_bounds__(256, 1) void topk_stream_kernel(TopkStreamArgs a) {
     RANGE_TS_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end
     RANGE_TS_STAMP(6);
+#ifdef RANGE_EXP_TS_STAMPS
+    if (lane == 0 && a.stamps) {   // sums over the loop: waiting for tiles / issuing LDS-DMA / arithmetic
+        a.stamps[(size_t)w_id * 8 + 3] = ts_wait;
+        a.stamps[(size_t)w_id * 8 + 7] = (ts_issue << 32) | (ts_comp & 0xFFFFFFFFull);
+    }
+#endif
 }
 
 // One workgroup per query.  Thread p owns the sorted list (L keys) of stream wave p (<= 1024).

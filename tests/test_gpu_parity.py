@@ -512,31 +512,31 @@ def test_topk_stream_exact_fallback(monkeypatch):
     tvx, tix = engx.topk_stream(e32, k)
     assert engx.topk_stream_exact_count() == B
     assert torch.equal(ti, tix) and torch.equal(tv, tvx)
-    # (ii) duplicates: rows r, r + 16*1024*t sit in the same lane of the same wave (a wave's tiles
-    # are 1024 = the wave count apart): 12 copies of a query's best row in ONE lane's rows
-    n_waves = 4 * 256
-    N2 = 16 * n_waves * 12 + 400
+    # (ii) duplicates: rows r, r + 16*n_waves*t sit in the same lane of the same wave (a wave's
+    # tiles are n_waves apart): `copies` copies of a query's best row in ONE lane's rows.  Up to 16
+    # queries run the 1-group kernel, more the 2-group kernel (both 4 waves in 256 workgroups).
     rng = np.random.default_rng(3)
-    big = rng.standard_normal((N2, 256)).astype(np.float32)
-    big /= np.linalg.norm(big, axis=1, keepdims=True)
-    qs = np.zeros((4, 256), np.float32)
-    for b in range(4):
-        base = 16 * b + 5
-        for t in range(12):
-            big[base + 16 * n_waves * t] = big[base]
-        qs[b] = big[base]
-    vals = rng.standard_normal((N2, 1024)).astype(np.float32)
-    xyz = rng.standard_normal((N2, 3)).astype(np.float32)
-    eng2 = _engine()
-    eng2.set_bank(big, vals, xyz)
-    tv2, ti2 = eng2.topk_stream(_dev(qs), k)
-    assert eng2.topk_stream_exact_count() == 4
-    s64 = qs.astype(np.float64) @ big.astype(np.float64).T
-    rv, ri = O.topk64(s64, k)
-    ti2 = ti2.cpu().numpy()
-    for b in range(4):   # the 12 copies first, lower rows first
-        assert np.array_equal(ti2[b, :12], 16 * b + 5 + 16 * n_waves * np.arange(12))
-    np.testing.assert_allclose(tv2.cpu().numpy(), rv, rtol=0, atol=6e-7)   # f32 dot of 256 terms near 1.0
+    for nq, n_waves, copies in ((4, 4 * 256, 12), (20, 4 * 256, 8)):
+        N2 = 16 * n_waves * copies + 400
+        big = rng.standard_normal((N2, 256)).astype(np.float32)
+        big /= np.linalg.norm(big, axis=1, keepdims=True)
+        qs = big[rng.integers(0, N2, nq)].copy()
+        for b in range(4):
+            base = 16 * b + 5
+            for t in range(copies):
+                big[base + 16 * n_waves * t] = big[base]
+            qs[b] = big[base]
+        eng2 = _engine()
+        eng2.set_bank(big, np.zeros((N2, 1024), np.float32), np.zeros((N2, 3), np.float32))
+        tv2, ti2 = eng2.topk_stream(_dev(qs), k)
+        assert eng2.topk_stream_exact_count() >= 4
+        s64 = qs.astype(np.float64) @ big.astype(np.float64).T
+        rv, ri = O.topk64(s64, k)
+        ti2 = ti2.cpu().numpy()
+        for b in range(4):   # the copies first, lower rows first
+            assert np.array_equal(ti2[b, :copies], 16 * b + 5 + 16 * n_waves * np.arange(copies))
+        np.testing.assert_allclose(tv2.cpu().numpy(), rv, rtol=0, atol=6e-7)   # f32 dot of 256 terms near 1.0
+        del eng2
 
 
 def test_encoder_edge_coordinates():
