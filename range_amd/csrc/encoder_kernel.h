@@ -200,7 +200,9 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
 // MODE 1 - the first layer for ONE column part of a 16-query tile (NT = the part's width / 64,
 // `part` = which), activated slice written to a.h1 - on n_parts times as many workgroups, then
 // MODE 2 - everything after the first layer, from a.h1 - per tile.
-template <int NT, int NW, int QT, int MODE = 0>
+// NWT >= NW waves in the workgroup: waves NW.. only generate features (MODE 1, where a part of few
+// columns has few n-tiles to compute but the whole feature set to generate).
+template <int NT, int NW, int QT, int MODE = 0, int NWT = NW>
 __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem, int part = 0) {
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
@@ -212,12 +214,15 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double DEG = 3.14159265358979323846 / 180.0;
 
-    // ---- SH generator state: thread = (query gq, slot-in-round gslot); threads 128..255 idle
+    // ---- SH generator state: thread = (query gq, slot-in-round gslot); the other threads idle
     //      (reference-faithful mode: every thread generates - thread = (query, slot, sub), the
     //      polynomials of an order are dealt to the NSUB sub-threads by degree)
-    constexpr int NSUB = NW * 64 / (ENC_QTILE * ENC_SLOTS_PER_ROUND);
-    const int gq = tid & 31, gslot = a.sh_desc ? (tid >> 5) & (ENC_SLOTS_PER_ROUND - 1) : tid >> 5;
-    const int gsub = tid >> 7;
+    constexpr int GQ = 16 * QT;                                     // queries of this workgroup
+    constexpr int NSUB = NWT * 64 / (GQ * ENC_SLOTS_PER_ROUND);
+    static_assert(MODE == 1 || NWT == NW, "generator-only waves exist in MODE 1 only");
+    const int gq = tid & (GQ - 1);
+    const int gslot = a.sh_desc ? (tid / GQ) & (ENC_SLOTS_PER_ROUND - 1) : tid / GQ;
+    const int gsub = tid / (GQ * ENC_SLOTS_PER_ROUND);
     double cx = 0, sx = 0, phi = 0;
     if (MODE != 2 && gslot < ENC_SLOTS_PER_ROUND) {
         const int64_t q = (q0 + gq < a.B) ? q0 + gq : a.B - 1;
@@ -239,7 +244,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     // reference's torch.pow delivers up to its last bit.  The sums below cancel by up to 1e14, so
     // they see every bit of their terms; the powers are shared through LDS ([32 queries][L]).
     double* pwt = red + 16 * ENC_QTILE;
-    if (MODE != 2 && a.sh_desc && tid < ENC_QTILE) {
+    if (MODE != 2 && a.sh_desc && tid < GQ) {
         double hi = 1.0, lo = 0.0;
         pwt[gq * L] = 1.0;
         for (int k = 1; k < L; ++k) {
@@ -262,7 +267,11 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         const int kp1 = a.slot_base[s_last];
         __syncthreads();   // previous round's fragment reads are done
         const int slot = s_first + gslot;
+#ifdef RANGE_EXP_ENC_NOGEN      // (timing experiment: no feature generation at all)
+        if (false) {
+#else
         if (a.sh_desc) {
+#endif
             // the generated functions Yl{l}_m{m} of this slot's orders, in the reference's order of
             // operations: every product and every sum rounded on its own (no fused multiply-add),
             // the terms of a sum left to right; degrees l = m + gsub, m + gsub + NSUB, ...
@@ -323,7 +332,11 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                 if (gsub == 0)
                     for (int pos = pos_m; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
             }
+#ifdef RANGE_EXP_ENC_NOGEN
+        } else if (false) {
+#else
         } else if (gslot < ENC_SLOTS_PER_ROUND && slot < s_last) {
+#endif
             int pos = a.slot_base[slot] - kp0;
             const int end = a.slot_base[slot + 1] - kp0;
             const int m_a = slot;
@@ -354,11 +367,13 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         __syncthreads();
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
                           ((int64_t)((MODE == 1 ? part * (a.part_cols >> 4) : 0) + wave * NTW) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
-        gemm_kpairs<NTW, QT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
+        if (NWT == NW || wave < NW)
+            gemm_kpairs<NTW, QT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
     }
 
     if (MODE == 1) {
         // the part's slice of h1 = sin(30 * (acc + b)) (location_encoder.py:119, 147-150) to HBM
+        if (NWT != NW && wave >= NW) return;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int n = part * a.part_cols + (wave * NTW + i) * 16 + (lane & 15);
@@ -472,11 +487,12 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
 // small-batch pair: first layer per (16-query tile, column part), then the rest per tile
 // (NWP waves: 8 where the part has at least 8 n-tiles - more threads for the feature generation,
 // which every part of a tile repeats)
+constexpr int ENC_PART_WAVES = 16;     // 4 per SIMD: the generator waits on table loads most of its time
 template <int NTP, int NWP>
-__global__ __launch_bounds__(NWP * 64, 1) void encoder_l1_part_kernel(EncArgs a) {
+__global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_l1_part_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / a.n_parts, part = blockIdx.x - tile * a.n_parts;
-    encoder_body<NTP, NWP, 1, 1>(a, (int64_t)tile * 16, smem, part);
+    encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a, (int64_t)tile * 16, smem, part);
 }
 
 template <int NT, int NW>

@@ -146,7 +146,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
     case NTP:                                                                                  \
         rc = set_dyn_lds(encoder_l1_part_kernel<NTP, NWP>, lds);                               \
         if (rc) return rc;                                                                     \
-        hipLaunchKernelGGL((encoder_l1_part_kernel<NTP, NWP>), dim3(tiles * S), dim3(NWP * 64), lds, s, a); \
+        hipLaunchKernelGGL((encoder_l1_part_kernel<NTP, NWP>), dim3(tiles * S), dim3(ENC_PART_WAVES * 64), lds, s, a); \
         break;
     switch (ntp) {
         RANGE_ENC_PART(1, 4)
