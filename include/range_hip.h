@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 3
+#define RANGE_ABI_VERSION 4
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -102,6 +102,19 @@ int range_set_sh_table(range_ctx* ctx, int32_t L, const double* front, const dou
 int range_set_bank(range_ctx* ctx, const float* keys, const float* values, const float* xyz,
                    int64_t n_rows, int64_t row_offset);
 int64_t range_bank_rows(const range_ctx* ctx);
+
+/* Opt-in arithmetic of the w @ V products of pass 2 (range/range.py:217, :236).  NOT in the
+ * reference; the default is what the reference computes.
+ *   RANGE_PV_EXACT  (default) exact float32 products (v_mfma_f32_16x16x4_f32)
+ *   RANGE_PV_BF16X3 both operands split into three bf16 planes, the six largest cross products
+ *                   accumulated in float32 (~2^-22 relative to the exact products); needs 6 B per
+ *                   bank value of extra device memory, built here or at the next range_set_bank;
+ *                   used by range_attend_kept / range_forward on kept logits only (a pass 2 that
+ *                   recomputes its logits stays exact).  Synchronous. */
+#define RANGE_PV_EXACT 0
+#define RANGE_PV_BF16X3 1
+int range_set_pv_mode(range_ctx* ctx, int32_t mode);
+int32_t range_get_pv_mode(const range_ctx* ctx);
 
 /* Kernel A.  Replaces self.loc_model(coords) and the normalisation of range/range.py:210-212
  * (spherical_harmonics.py:27-42 + location_encoder.py:98-112, fused, float64) and the query half

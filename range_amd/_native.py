@@ -36,7 +36,9 @@ SYMBOLS = (
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
+    "range_set_pv_mode", "range_get_pv_mode",
 )
+PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
 
 class EncoderDesc(C.Structure):
@@ -96,9 +98,12 @@ def load_library() -> C.CDLL:
     lib.range_topk_stream_exact_count.argtypes = [vp, C.POINTER(i64)]
     lib.range_topk_stream_timed.argtypes = [vp, vp, i64, i32, vp, vp, i32, C.POINTER(f32), vp]
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
+    lib.range_set_pv_mode.argtypes = [vp, i32]
+    lib.range_get_pv_mode.argtypes = [vp]
+    lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 3:
+    if lib.range_abi_version() != 4:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
     flags = lib.range_build_flags().decode()
     if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":
@@ -194,6 +199,19 @@ class HipEngine:
                                                  xyz.ctypes.data, n, row_offset))
         self.n_rows = n
         self.row_offset = row_offset
+
+    def set_pv_mode(self, mode: str = "exact") -> None:
+        """Arithmetic of pass 2's w @ V: "exact" (default: float32 products, what the reference
+        computes) or the opt-in "bf16x3" (three bf16 planes per operand, six cross products; see
+        include/range_hip.h: range_set_pv_mode)."""
+        if mode not in PV_MODES:
+            raise ValueError(f"pv_mode must be one of {sorted(PV_MODES)}, got {mode!r}")
+        _check(self.lib, self.lib.range_set_pv_mode(self._h, PV_MODES[mode]))
+
+    @property
+    def pv_mode(self) -> str:
+        m = self.lib.range_get_pv_mode(self._h)
+        return {v: k for k, v in PV_MODES.items()}[m]
 
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self) -> int:

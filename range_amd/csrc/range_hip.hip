@@ -19,6 +19,7 @@
 #include "host_plan.h"
 #include "attend_kernels.h"
 #include "topk_stream.h"
+#include "attend_bf16x3.h"
 #include "encoder_kernel.h"
 
 using namespace range_hip;
@@ -62,6 +63,10 @@ struct range_ctx {
     bool has_bank = false;
     int64_t n_rows = 0, n_pad = 0, row_offset = 0;
     DevBuf<float> d_keys, d_values, d_xyz4;
+    // opt-in pass 2 on bf16 planes of the values (attend_bf16x3.h): RANGE_PV_EXACT unless asked for
+    int pv_mode = RANGE_PV_EXACT;
+    DevBuf<uint32_t> d_vplanes;       // (ceil(n_rows/32), 4 pieces, 16 tiles, 3 planes, 64 lanes, 8 bf16)
+    int64_t vplanes_groups = 0;
     // workspace
     DevBuf<float> ws_stats_parts, ws_slabs, ws_stats, ws_ehat32, ws_xq, ws_partial, ws_cand_val;
     // logits kept by the last range_scan_stats(keep_logits = 1): kept_B queries x kept_blocks
@@ -229,6 +234,21 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     }
 #undef RANGE_ENC_CASE
     HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
+// the three bf16 planes of the bank's values in MFMA fragment order (attend_bf16x3.h); 6 B per value
+int build_vplanes(range_ctx* c) {
+    const int64_t n_groups = (c->n_rows + 31) / 32;
+    if (c->d_vplanes.ensure((size_t)n_groups * (PVB_GROUP_BYTES / 4)) != hipSuccess)
+        return fail(RANGE_ERR_NOMEM, "out of device memory for the bf16 planes of the values (%lld MB)",
+                    (long long)(n_groups * PVB_GROUP_BYTES >> 20));
+    const int64_t threads = n_groups * 64 * 64;
+    hipLaunchKernelGGL(vplanes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, c->d_values.p,
+                       c->n_pad, n_groups, reinterpret_cast<u32x4*>(c->d_vplanes.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    c->vplanes_groups = n_groups;
     return RANGE_OK;
 }
 
@@ -443,8 +463,21 @@ int range_set_bank(range_ctx* c, const float* keys, const float* values, const f
     c->n_pad = n_pad;
     c->row_offset = row_offset;
     c->has_bank = true;
+    c->vplanes_groups = 0;
+    if (c->pv_mode == RANGE_PV_BF16X3) return build_vplanes(c);
     return RANGE_OK;
 }
+
+int range_set_pv_mode(range_ctx* c, int32_t mode) {
+    if (!c) return fail(RANGE_ERR_INVALID, "null argument");
+    if (mode != RANGE_PV_EXACT && mode != RANGE_PV_BF16X3) return fail(RANGE_ERR_INVALID, "unknown pv mode %d", mode);
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    c->pv_mode = mode;
+    if (mode == RANGE_PV_BF16X3 && c->has_bank && c->vplanes_groups == 0) return build_vplanes(c);
+    return RANGE_OK;
+}
+int32_t range_get_pv_mode(const range_ctx* c) { return c ? c->pv_mode : -1; }
 
 static int encode_impl(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
                        float* xq32, double* eraw64, range_stream_t stream) {
@@ -871,7 +904,21 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
         a.logits = c->ws_logits.p;
         a.qt_offset = (int32_t)(kept_first / QTILE);
         ProfScope ps(c, RANGE_PROF_ATTEND, s);
-        if (geo) {
+        if (c->pv_mode == RANGE_PV_BF16X3) {
+            // opt-in: w @ V on three bf16 planes of both operands (attend_bf16x3.h)
+            const int32_t n_groups = (a.n_blocks + 1) / 2;
+            if (c->vplanes_groups != n_groups) return fail(RANGE_ERR_STATE, "bf16 planes of the values are missing");
+            const char* planes = reinterpret_cast<const char*>(c->d_vplanes.p);
+            if (geo) {
+                rc = set_dyn_lds(attend_bf16x3_kernel<true>, PVB_LDS_BYTES);
+                if (rc) return rc;
+                hipLaunchKernelGGL(attend_bf16x3_kernel<true>, grid, block, PVB_LDS_BYTES, s, a, planes, n_groups);
+            } else {
+                rc = set_dyn_lds(attend_bf16x3_kernel<false>, PVB_LDS_BYTES);
+                if (rc) return rc;
+                hipLaunchKernelGGL(attend_bf16x3_kernel<false>, grid, block, PVB_LDS_BYTES, s, a, planes, n_groups);
+            }
+        } else if (geo) {
             rc = set_dyn_lds(attend_stored_kernel<true>, ATTEND_STORED_LDS_BYTES);
             if (rc) return rc;
             hipLaunchKernelGGL(attend_stored_kernel<true>, grid, block, ATTEND_STORED_LDS_BYTES, s, a);
