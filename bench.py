@@ -310,6 +310,7 @@ def main():
     # ---- parity of the timed result (outside the timed region): 64 of rank 0's rows against the
     #      oracle in the reference's float32 op order and in exact float64
     parity = None
+    parity_rows = None
     if rank == 0:
         from oracle import range_oracle as O     # checker only
         obank = O.prep_bank(*bank_arrays)
@@ -329,6 +330,7 @@ def main():
                   "max_abs_vs_f64_oracle": float(np.abs(got[:, :1024] - ref64).max()),
                   "ehat_max_abs_lat_le_45": float(np.abs(got_e - e)[band].max()),
                   "ehat_max_abs_all_latitudes": float(np.abs(got_e - e).max())}
+        parity_rows = {"idx": idx, "exact": got[:, :1024].copy(), "ref64": ref64}
         if not parity["ehat_max_abs_lat_le_45"] < 1e-6:
             raise SystemExit(f"bench parity failed: {parity}")
         if not parity["max_abs_vs_reference_f32_order"] < 1e-4:
@@ -369,9 +371,11 @@ def main():
         engc.close()
     scan = None
     host_contract = None
+    opt_in = None
     if world == 1 and not sharded and not a.no_extras:
         scan = scan_roofline(eng, synth, torch, dev, N, bank)
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
+        opt_in = opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev)
 
     if rank == 0:
         att_ms, att_n = m["prof"]["attend"]
@@ -459,12 +463,39 @@ def main():
         if host_contract is not None:
             res["value_host_contract"] = host_contract["value"]
             res["host_contract"] = host_contract
+        if opt_in is not None:
+            res["opt_in_bf16x3"] = opt_in
         if world == 1 and a.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev):
+    """The same step with the OPT-IN arithmetic of pass 2 (load_model(..., pv_mode="bf16x3"):
+    w @ V on three bf16 planes of both operands).  Never `value`: the headline is the exact float32
+    path.  Reported with its error on the rows of the parity check: against the float64 oracle
+    (next to the exact kernel's own error there) and against the exact kernel's output."""
+    from range_amd import _native
+    import numpy as np
+    eng.set_pv_mode("bf16x3")
+    try:
+        m = measure(a.scaling, max(3, a.steps // 4), 2)
+    finally:
+        eng.set_pv_mode("exact")
+    steps = max(3, a.steps // 4)
+    got = m["out"][torch.from_numpy(parity_rows["idx"]).to(dev)].cpu().numpy()[:, :1024]
+    att_ms, att_n = m["prof"]["attend"]
+    return {"what": "opt-in pv_mode='bf16x3' (never the default, never `value`)",
+            "value": m["B"] * steps / m["dt"], "unit": "geo-embeddings/s",
+            "ms_per_step": m["dt"] / steps * 1e3, "pass2_ms": att_ms / att_n,
+            "bf16_tflops": m["B"] * eng.n_rows * 1024 * 2 * 6 / (att_ms / att_n * 1e-3) / 1e12,
+            "frac_of_bf16_peak": m["B"] * eng.n_rows * 1024 * 2 * 6 / (att_ms / att_n * 1e-3) / 1e12 / 2500.0,
+            "max_abs_vs_f64_oracle": float(np.abs(got - parity_rows["ref64"]).max()),
+            "exact_kernel_max_abs_vs_f64_oracle": float(np.abs(parity_rows["exact"] - parity_rows["ref64"]).max()),
+            "max_abs_vs_exact_kernel": float(np.abs(got - parity_rows["exact"]).max())}
 
 
 def scan_roofline(eng, synth, torch, dev, N, bank):

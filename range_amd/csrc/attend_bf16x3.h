@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
         cur.h[0] = h[0]; cur.h[1] = h[1]; cur.m[0] = m[0]; cur.m[1] = m[1]; cur.l[0] = l[0]; cur.l[1] = l[1];
         weights(1, h, m, l);
         cur.h[2] = h[0]; cur.h[3] = h[1]; cur.m[2] = m[0]; cur.m[3] = m[1]; cur.l[2] = l[0]; cur.l[3] = l[1];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // slot 0 is read before it is refilled
+        // slot 0 is refilled next: this wave's S tile has been read (lgkmcnt), and the X tile - one
+        // copy shared by the four waves, each of which writes it - by every wave (barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         nxt = cur;
         issue_sx(3);
 #pragma unroll

@@ -21,7 +21,10 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
             checkpoints evaluate the reference's own generated polynomials, so embeddings agree
             with the reference at every latitude) or 'exact' (the mathematically exact basis);
             ``sh_source`` - a generated ``spherical_harmonics_ylm.py`` to take the polynomial
-            coefficients from (default: regenerated, range_amd/sh_table.py).
+            coefficients from (default: regenerated, range_amd/sh_table.py); ``pv_mode`` -
+            'exact' (default: float32 products like the reference, range.py:217/:236) or the
+            opt-in 'bf16x3' (retrieval products on the bf16 matrix cores, both operands split in
+            three planes: ~1.5x the throughput, agreement with the exact products to ~1e-7).
     """
     if pretrained_path is None:
         raise ValueError("Please provide the pretrained model path.")      # load_model.py:31-32
@@ -34,7 +37,7 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
         beta = None
     args = Namespace(location_model_name=model_name, pretrained_path=pretrained_path,
                      device=device, range_db=db_path, beta=beta)           # :45-46
-    for opt in ("sh_eval", "sh_source"):
+    for opt in ("sh_eval", "sh_source", "pv_mode"):
         if opt in kwargs:
             setattr(args, opt, kwargs[opt])
     model = LocationEncoder(args)

@@ -76,8 +76,13 @@ def sh_table_for(enc: EncoderParams, sh_eval: Optional[str] = None, sh_source: O
 
 
 def make_engine(enc: EncoderParams, bank: Optional[PreparedBank], device, row_offset: int = 0,
-                sh_eval: Optional[str] = None, sh_source: Optional[str] = None):
+                sh_eval: Optional[str] = None, sh_source: Optional[str] = None,
+                pv_mode: Optional[str] = None):
+    """``pv_mode``: None / 'exact' (the reference's float32 products) or the opt-in 'bf16x3'
+    (include/range_hip.h: range_set_pv_mode)."""
     eng = _native.HipEngine(device)
+    if pv_mode is not None:
+        eng.set_pv_mode(pv_mode)
     mode = _native.SH_ANALYTIC if enc.harmonics_calculation == "analytic" else _native.SH_CLOSED_FORM
     eng.set_encoder(enc.legendre_polys, enc.hidden, enc.num_hidden_layers, enc.embed_dim, mode,
                     enc.weights, enc.biases, sh_table=sh_table_for(enc, sh_eval, sh_source))
@@ -121,7 +126,8 @@ class LocationEncoder(nn.Module):
             self.n_bank_rows = bank.n_rows
             self._device = _device_of(args.device)
             self.engine = make_engine(enc, bank, self._device, sh_eval=getattr(args, "sh_eval", None),
-                                      sh_source=getattr(args, "sh_source", None))
+                                      sh_source=getattr(args, "sh_source", None),
+                                      pv_mode=getattr(args, "pv_mode", None))
         elif self.location_model_name == "SatCLIP":                     # range.py:117-122
             print("Using SatCLIP")
             enc = read_checkpoint(args.pretrained_path)

@@ -102,3 +102,29 @@ def test_bf16x3_planes_follow_the_bank():
     np.testing.assert_allclose(got, ref64, rtol=0, atol=2e-5)
     with pytest.raises(ValueError):
         eng.set_pv_mode("fp8")
+
+
+def test_load_model_pv_mode(tmp_path):
+    """load_model(..., pv_mode='bf16x3') is the opt-in; the default model stays on exact float32
+    products.  Both return the reference's (B,1280) float64 ndarray; they agree to 1e-6, the
+    embedding half bit for bit; the sweep and a second beta go through the same kernel."""
+    from range_amd import load_model
+    ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=10, hidden=64, seed=5)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 5000, 3)
+    q = torch.from_numpy(synth.make_queries(700, seed=8, lat_max=90.0)).to("cuda:0")
+    exact = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db)
+    fast = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, pv_mode="bf16x3")
+    assert exact.engine.pv_mode == "exact" and fast.engine.pv_mode == "bf16x3"
+    a, b = exact(q), fast(q)
+    assert isinstance(b, np.ndarray) and b.dtype == np.float64 and b.shape == (700, 1280)
+    assert np.array_equal(a[:, 1024:], b[:, 1024:])
+    np.testing.assert_allclose(b[:, :1024], a[:, :1024], rtol=0, atol=1e-6)
+    assert not np.array_equal(a[:, :1024], b[:, :1024])          # it IS another arithmetic
+    sa, sb = exact.sweep(q, [0.0, 0.3, 1.0]), fast.sweep(q, [0.0, 0.3, 1.0])
+    np.testing.assert_allclose(np.asarray(sb), np.asarray(sa), rtol=0, atol=1e-6)
+    r = load_model("RANGE", pretrained_path=ck, device="cuda:0", db_path=db, pv_mode="bf16x3")
+    np.testing.assert_allclose(r(q)[:, :1024],
+                               load_model("RANGE", pretrained_path=ck, device="cuda:0", db_path=db)(q)[:, :1024],
+                               rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, pv_mode="fp8")

@@ -2,7 +2,8 @@
 # The rocprofv3 passes behind profiles/rNN (run on the GPU box from the repo root):
 #   tools/profile_bench.sh r02
 # bench line, kernel-trace stats of the same command, three separate --pmc passes (SQ/GRBM,
-# FETCH_SIZE, WRITE_SIZE+TCC) as MI355X_MICROARCH.md prescribes, and the small-batch top-k scan.
+# FETCH_SIZE, WRITE_SIZE+TCC) as MI355X_MICROARCH.md prescribes, the small-batch top-k scan, and
+# the two arithmetic modes of pass 2 side by side (tools/pv_modes.py).
 # Everything lands under gpurun_out/prof_<tag>/; copy the summaries into profiles/<tag>/ afterwards
 # (profiles/pmc_summarize.py condenses the counter files).
 set -e
@@ -22,6 +23,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-form
 RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan1 -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan.log 2>&1
 RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan1_pmc -o p -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1_pmc.log 2>&1
+# the opt-in pass 2 on bf16 planes next to the exact one: times + error vs the float64 oracle, kernel trace, fetched bytes
+python3 $R/tools/pv_modes.py --json > $O/pv_modes.json 2> $O/pv_modes.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pv -o pv -- python3 $R/tools/pv_modes.py > $O/pv.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pv_pmc -o p -- python3 $R/tools/pv_modes.py > $O/pv_pmc.log 2>&1
+find $O/pv -name "*kernel_stats.csv" -exec cp {} $O/pv_modes_kernel_stats.csv \;
 python3 $R/profiles/pmc_summarize.py $O/pmc1 $O/pmc2 $O/pmc3 > $O/pmc_summary.json
 cp $O/ks/ks_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 cut -c1-300 $O/bench_line.json
