@@ -34,10 +34,23 @@ namespace range_hip {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PVB_PIECE_BYTES = 16 * 3 * 1024;                 // 16 column tiles x 3 planes x 1 KB
-constexpr int PVB_GROUP_BYTES = 4 * PVB_PIECE_BYTES;           // 32 rows x 1024 columns x 6 B
-// LDS map (bytes): V ring 3 x 48 KB | S ring 3 x 4 KB | X ring 3 x 256 B = 160,512 B
-constexpr int PVB_LDS_BYTES = 3 * PVB_PIECE_BYTES + 3 * 4096 + 3 * 256;
+// column tiles per LDS piece: 16 (3 ring slots of 48 KB, 96 KB in flight) or 8 (6 slots of 24 KB,
+// 120 KB in flight, twice the barriers: measured 9.04 ms against 8.70 - the stream is not waiting
+// for latency, more bytes in flight do not help)
+#ifndef RANGE_PVB_TILES
+#define RANGE_PVB_TILES 16
+#endif
+constexpr int PVB_TP = RANGE_PVB_TILES;
+static_assert(PVB_TP == 16 || PVB_TP == 8, "piece of 16 or 8 column tiles");
+constexpr int PVB_NP = 64 / PVB_TP;                            // pieces (= steps) per 32-row group
+constexpr int PVB_PIECE_BYTES = PVB_TP * 3 * 1024;             // column tiles x 3 planes x 1 KB
+constexpr int PVB_SLOTS = 144 * 1024 / PVB_PIECE_BYTES;        // V ring slots
+constexpr int PVB_AHEAD = PVB_SLOTS - 1;                       // a piece is requested this many steps ahead
+constexpr int PVB_OPS = PVB_TP * 3 / 4;                        // LDS-DMA operations per wave and piece
+constexpr int PVB_WAVE_BYTES = PVB_PIECE_BYTES / 4;            // a wave's share of a piece
+constexpr int PVB_GROUP_BYTES = 64 * 3 * 1024;                 // 32 rows x 1024 columns x 6 B
+// LDS map (bytes): V ring 144 KB | S ring 3 x 4 KB | X ring 3 x 256 B = 160,512 B
+constexpr int PVB_LDS_BYTES = PVB_SLOTS * PVB_PIECE_BYTES + 3 * 4096 + 3 * 256;
 
 // round-to-nearest-even float32 -> bf16 of two values, packed (lo = a, hi = b)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
@@ -142,9 +155,9 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
     const uint32_t vring_lds = lds0;
-    const uint32_t sring_lds = lds0 + 3 * PVB_PIECE_BYTES;
+    const uint32_t sring_lds = lds0 + PVB_SLOTS * PVB_PIECE_BYTES;
     const uint32_t xring_lds = sring_lds + 3 * 4096;
-    const char* sring_b = smem + 3 * PVB_PIECE_BYTES;
+    const char* sring_b = smem + PVB_SLOTS * PVB_PIECE_BYTES;
     const char* xring_b = sring_b + 3 * 4096;
 
     const int lane = threadIdx.x & 63;
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
     const int g0 = (int)(((int64_t)split * n_groups) / a.n_splits);
     const int g1 = (int)(((int64_t)(split + 1) * n_groups) / a.n_splits);
     const int nG = g1 - g0;
-    const int n_steps = 4 * nG;
+    const int n_steps = PVB_NP * nG;
     const int64_t q = (int64_t)qt * QTILE + wave * 16 + (lane & 15);
     const int64_t qtile_kept = (int64_t)qt + a.qt_offset;
 
@@ -192,11 +205,11 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
                  sring_lds + slot * 4096 + wave * 1024);
         dma_b32(a.xyz4 + (int64_t)b * BLK * 4, (uint32_t)(lane << 2), xring_lds + slot * 256);
     };
-    // this wave's quarter (12 KB) of the piece of step st into ring slot vslot: op `i` of 12
+    // this wave's quarter of the piece of step st into ring slot vslot: op `i` of PVB_OPS
     auto issue_v = [&](int st, int vslot, int i) __attribute__((always_inline)) {
         const int sc = min(st, n_steps - 1);
-        const char* src = vplanes + ((int64_t)g0 * 4 + sc) * PVB_PIECE_BYTES + wave * 12288 + (i >> 2) * 4096;
-        if ((i & 3) == 0) dma_group_begin(vring_lds + vslot * PVB_PIECE_BYTES + wave * 12288 + (i >> 2) * 4096);
+        const char* src = vplanes + ((int64_t)g0 * PVB_NP + sc) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES + (i >> 2) * 4096;
+        if ((i & 3) == 0) dma_group_begin(vring_lds + vslot * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES + (i >> 2) * 4096);
         dma_b128_q(src, vvoff, i & 3);
     };
     // weights of bank block b_first + bb (4 per lane) -> packed bf16 planes, two words each
@@ -237,11 +250,15 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
         // copy shared by the four waves, each of which writes it - by every wave (barrier)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         nxt = cur;
-        issue_sx(3);
+        // the first PVB_AHEAD pieces, with S / X of block 3 where the steady state has it relative to
+        // the pieces (the waits of the first steps count the same operations as all later ones)
+        if (PVB_NP == 4) issue_sx(3);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) issue_v(0, 0, i);
+        for (int pc = 0; pc < PVB_AHEAD; ++pc) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) issue_v(1, 1, i);
+            for (int i = 0; i < PVB_OPS; ++i) issue_v(pc, pc, i);
+            if (PVB_NP == 8 && pc == 0) issue_sx(3);
+        }
     }
 
     int vs = 0;                                   // ring slot of the current step
@@ -253,63 +270,66 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
     auto nohook = [](int) __attribute__((always_inline)) {};
     for (int gi = 0; gi < nG; ++gi) {
 #pragma unroll
-        for (int P = 0; P < 4; ++P) {
-            const int st = 4 * gi + P;
-            const int vs2 = vs == 0 ? 2 : vs - 1;            // (st + 2) % 3 == (st - 1) % 3
-            // the piece of this step has landed when only the operations issued during the previous
-            // step are outstanding: 12 (V) after steps 1 and 3, 14 (V + S + X) after steps 0 and 2
-            if (P & 1) RANGE_WAIT_BARRIER(14);
+        for (int P = 0; P < PVB_NP; ++P) {
+            const int st = PVB_NP * gi + P;
+            const int vs2 = vs == 0 ? PVB_SLOTS - 1 : vs - 1;       // slot of step st + PVB_AHEAD == that of st - 1
+            // The piece of this step has landed when only the operations issued during the last
+            // PVB_AHEAD - 1 steps are outstanding.  16-tile pieces: those of the previous step, 12 (V)
+            // after steps 1 and 3, 14 (V + S + X) after steps 0 and 2; 8-tile pieces: four steps of
+            // 6, one of them with S + X.
+            if (PVB_NP == 8) RANGE_WAIT_BARRIER(26);
+            else if (P & 1) RANGE_WAIT_BARRIER(14);
             else RANGE_WAIT_BARRIER(12);
             const char* vslot = smem + vs * PVB_PIECE_BYTES + lane * 16;
             PvbB b0 = pvb_read(vslot, 0), b1 = pvb_read(vslot, 1);
-            pvb_tile(acc[16 * ((P + 3) & 3) + 15], cur, carry, nohook);
+            pvb_tile(acc[PVB_TP * ((P + PVB_NP - 1) % PVB_NP) + PVB_TP - 1], cur, carry, nohook);
             if (P == 0) {                                     // (in the first group nxt == cur)
                 asm volatile("s_nop 1");                      // the carried MFMAs still read cur
                 cur = nxt;
             }
-            // LDS-DMA of this step: the piece two steps ahead (this wave's 12 KB of it), then S / X
-            const char* vsrc = vplanes + ((int64_t)g0 * 4 + min(st + 2, n_steps - 1)) * PVB_PIECE_BYTES + wave * 12288;
-            const uint32_t vdst = vring_lds + vs2 * PVB_PIECE_BYTES + wave * 12288;
+            // LDS-DMA of this step: the piece PVB_AHEAD steps ahead (this wave's quarter), then S / X
+            const char* vsrc = vplanes + ((int64_t)g0 * PVB_NP + min(st + PVB_AHEAD, n_steps - 1)) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
+            const uint32_t vdst = vring_lds + vs2 * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
 #pragma unroll
-            for (int ct = 0; ct < 15; ++ct) {
+            for (int ct = 0; ct < PVB_TP - 1; ++ct) {
                 PvbB b2;
-                pvb_tile(acc[16 * P + ct], cur, b0, [&](int i) __attribute__((always_inline)) {
-                    const int cr = ct + 2 < 16 ? ct + 2 : 15;
+                pvb_tile(acc[PVB_TP * P + ct], cur, b0, [&](int i) __attribute__((always_inline)) {
+                    const int cr = ct + 2 < PVB_TP ? ct + 2 : PVB_TP - 1;
                     if (i == 0) b2.h = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 0) * 1024);
                     else if (i == 1) b2.m = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 1) * 1024);
                     else if (i == 2) b2.l = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 2) * 1024);
                     else if (i == 3) {
 #ifndef RANGE_EXP_PVB_NODMA
-                        if (ct < 12) {
+                        if (ct < PVB_OPS) {
                             if ((ct & 3) == 0) dma_group_begin(vdst + (ct >> 2) * 4096);
                             dma_b128_q(vsrc + (ct >> 2) * 4096, vvoff, ct & 3);
-                        } else if (ct == 12 && (P & 1) == 0) {
-                            issue_sx(2 * gi + 4 + (P >> 1));
+                        } else if (ct == PVB_OPS && P % (PVB_NP / 2) == 0) {
+                            issue_sx(2 * gi + 4 + P / (PVB_NP / 2));
                         }
 #endif
-                    } else if (i == 5 && ct == 14) {
+                    } else if (i == 5 && ct == PVB_TP - 2) {
                         asm volatile("s_nop 1");             // the step ends: whatever follows may be vector ALU
                     }
                 });
                 b0 = b1; b1 = b2;
             }
-            carry = b0;                                      // column tile 15
-            // the next group's weights: its first block after step 1, its second after step 3 (cut
-            // into pieces and placed in the MFMA gaps they took the same time: the vector ALU work
-            // costs its issue slots either way)
+            carry = b0;                                      // the step's last column tile
+            // the next group's weights: its first block after the first half of the steps, its second
+            // after the last (cut into pieces and placed in the MFMA gaps they took the same time:
+            // the vector ALU work costs its issue slots either way)
 #ifdef RANGE_EXP_PVB_NOW
             if (false) {
 #else
-            if (P & 1) {
+            if (P % (PVB_NP / 2) == PVB_NP / 2 - 1) {
 #endif
                 uint32_t h[2], m[2], l[2];
-                weights(2 * gi + 2 + (P >> 1), h, m, l);
-                const int o = P & 2;
+                weights(2 * gi + 2 + P / (PVB_NP / 2), h, m, l);
+                const int o = 2 * (P / (PVB_NP / 2));
                 nxt.h[o] = h[0]; nxt.h[o + 1] = h[1];
                 nxt.m[o] = m[0]; nxt.m[o + 1] = m[1];
                 nxt.l[o] = l[0]; nxt.l[o + 1] = l[1];
             }
-            vs = vs == 2 ? 0 : vs + 1;
+            vs = vs == PVB_SLOTS - 1 ? 0 : vs + 1;
         }
     }
     if (nG > 0) {
