@@ -43,8 +43,11 @@ def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 class ShardedRange:
     """RANGE / RANGE+ forward over a row-sharded bank.  ``engine`` holds THIS rank's rows."""
 
-    #: queries per rank and chunk below which a forward is not split further
-    min_chunk = 2048
+    #: scanned queries (all ranks' rows of a chunk) below which a forward is not split further:
+    #: a chunk's pass 2 must still fill the chip (64 query tiles x the bank splits); measured on
+    #: one GPU in the shape of an 8-rank strong-scaling step (tools/shard_emulate.py --chunks):
+    #: two chunks of 5 000 scanned queries cost nothing, and hide half of the partials' exchange
+    min_chunk = 4096
 
     def __init__(self, engine, model_name: str = "RANGE+", beta: Optional[float] = 0.5,
                  group=None, n_chunks: Optional[int] = None):
@@ -169,7 +172,7 @@ class ShardedRange:
         query-tile size: a chunk then starts on a tile of the kept logits)."""
         W = self.world
         n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
-        n_chunks = max(1, min(n_chunks, B // self.min_chunk if B >= self.min_chunk else 1))
+        n_chunks = max(1, min(n_chunks, (W * B) // self.min_chunk))
         cuts = sorted({min(B, ((B * c) // n_chunks + 32) // 64 * 64) for c in range(1, n_chunks)})
         bounds = [0] + [c for c in cuts if 0 < c < B] + [B]
         return list(zip(bounds[:-1], bounds[1:]))

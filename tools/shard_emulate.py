@@ -10,7 +10,7 @@ communication, for both scaling modes of bench.py:
 The time of this against the single-GPU step bounds the scaling efficiency from above (the
 exchange - all-gather of 1 040 B per query, all-reduce of 8 B per query, all-to-all of 4 KB per
 query - comes on top; DESIGN.md section 6 prices it).
-Usage: python tools/shard_emulate.py [--json] [N ...]"""
+Usage: python tools/shard_emulate.py [--json] [--chunks k] [N ...]"""
 import json
 import os
 import sys
@@ -26,6 +26,9 @@ w = synth.make_encoder_weights(40, 512, 256, 2, 1234)
 full = prepare_bank(*synth.make_bank(100000, 2024))
 TABLE = sh_table.generate_table(40)      # load_model's default for an analytic checkpoint
 as_json = "--json" in sys.argv
+FORCE_CHUNKS = int(sys.argv[sys.argv.index("--chunks") + 1]) if "--chunks" in sys.argv else 0
+if FORCE_CHUNKS:
+    del sys.argv[sys.argv.index("--chunks"):sys.argv.index("--chunks") + 2]
 worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
 base = {}
 for mode in ("strong", "weak"):
@@ -39,8 +42,10 @@ for mode in ("strong", "weak"):
         x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
         e64, e32, xq = eng.encode(x)
         e32_all, xq_all = e32.repeat(W, 1).contiguous(), xq.repeat(W, 1).contiguous()
-        # ShardedRange._chunk_bounds: 4 chunks when a rank's batch is large enough, else 1
-        n_chunks = max(1, min(4, B // 2048)) if W > 1 else 1
+        # ShardedRange._chunk_bounds: up to 4 chunks of at least 4096 scanned queries (--chunks k forces k)
+        n_chunks = max(1, min(4, (W * B) // 4096)) if W > 1 else 1
+        if FORCE_CHUNKS:
+            n_chunks = FORCE_CHUNKS
         cuts = [0] + [((B * c) // n_chunks + 32) // 64 * 64 for c in range(1, n_chunks)] + [B]
 
         def step():
