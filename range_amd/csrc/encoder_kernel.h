@@ -68,11 +68,19 @@ struct EncArgs {
     const SHDesc* sh_desc;      // [L*L] at l*L+m
     const double* sh_coef;
     const int32_t* sh_pow;
-    // small batches: the first layer split over n_parts workgroups per 16-query tile (each takes
-    // part_cols hidden columns and writes its activated slice to h1), the rest in a second kernel
-    double* h1;                 // (ceil(B/16)*16, H) f64
+    // small batches: the first layer split over n_parts x n_kparts workgroups per 16-query tile
+    // (each takes part_cols hidden columns and a range of the K slots, and writes its raw partial
+    // sums to h1); the second kernel sums the K parts, adds the bias and activates
+    double* h1;                 // (n_kparts, ceil(B/16)*16, H) f64
     int32_t n_parts;
     int32_t part_cols;
+    int32_t n_kparts;
+    // ... and the second layer over n_parts2 column parts per tile (MODE 3: activated slice to
+    // h2); the last kernel then starts from h2 (rest_from = 1) instead of the partial sums of h1
+    double* h2;                 // (ceil(B/16)*16, H) f64
+    int32_t n_parts2;
+    int32_t part2_cols;
+    int32_t rest_from;
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -197,16 +205,22 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
 // round half-size workgroups (EncArgs::n_wg32), which finish in about half the time.
 // MODE 0: the whole encoder in one workgroup.  Small batches leave most CUs idle and every
 // workgroup streams all 9.5 MB of weights on its own (0.28 ms, whatever the batch): they run
-// MODE 1 - the first layer for ONE column part of a 16-query tile (NT = the part's width / 64,
-// `part` = which), activated slice written to a.h1 - on n_parts times as many workgroups, then
-// MODE 2 - everything after the first layer, from a.h1 - per tile.
+// MODE 1 - the first layer for ONE column part (NT = the part's width / 64, `part` = which) and
+// ONE range of K slots (`kpart`: a range of slots means that share of the features to generate
+// and of the weights to stream) of a 16-query tile, raw partial sums to a.h1 - on n_parts x
+// n_kparts times as many workgroups, then
+// MODE 2 - everything after the first layer per tile: h1 = sin(30 (sum of the K parts + b)).
+// Where there are CUs to spare for it too, the second layer (a third of one workgroup's remaining
+// chain) runs as MODE 3 - ONE column part of the second layer, activated slice to a.h2 - and
+// MODE 2 starts from a.h2 (a.rest_from = 1).
 // NWT >= NW waves in the workgroup: waves NW.. only generate features (MODE 1, where a part of few
 // columns has few n-tiles to compute but the whole feature set to generate).
 template <int NT, int NW, int QT, int MODE = 0, int NWT = NW>
-__device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem, int part = 0) {
+__device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem, int part = 0,
+                                             int kpart = 0) {
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
-    static_assert(NTW * NW == 4 * NT && (MODE == 1 || EW * NW == 16), "n-tiles must divide among the waves");
+    static_assert(NTW * NW == 4 * NT && (MODE == 1 || MODE == 3 || EW * NW == 16), "n-tiles must divide among the waves");
     double* lds = reinterpret_cast<double*>(smem);
     double* red = lds + a.lds_main_doubles;      // [NW waves][32 queries]
 
@@ -224,7 +238,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const int gslot = a.sh_desc ? (tid / GQ) & (ENC_SLOTS_PER_ROUND - 1) : tid / GQ;
     const int gsub = tid / (GQ * ENC_SLOTS_PER_ROUND);
     double cx = 0, sx = 0, phi = 0;
-    if (MODE != 2 && gslot < ENC_SLOTS_PER_ROUND) {
+    if (MODE < 2 && gslot < ENC_SLOTS_PER_ROUND) {
         const int64_t q = (q0 + gq < a.B) ? q0 + gq : a.B - 1;
         phi = (a.lonlat[2 * q] + 180.0) * DEG;                    // spherical_harmonics.py:31
         const double theta = (a.lonlat[2 * q + 1] + 90.0) * DEG;  // :32
@@ -244,7 +258,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     // reference's torch.pow delivers up to its last bit.  The sums below cancel by up to 1e14, so
     // they see every bit of their terms; the powers are shared through LDS ([32 queries][L]).
     double* pwt = red + 16 * ENC_QTILE;
-    if (MODE != 2 && a.sh_desc && tid < GQ) {
+    if (MODE < 2 && a.sh_desc && tid < GQ) {
         double hi = 1.0, lo = 0.0;
         pwt[gq * L] = 1.0;
         for (int k = 1; k < L; ++k) {
@@ -258,11 +272,15 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         }
     }
     // (made visible to the other generator threads by the barrier that opens the first round)
-    for (int rnd_i = 0; MODE != 2 && rnd_i < a.n_rounds; ++rnd_i) {
+    // the slots of this workgroup: all of them, or the kpart-th of n_kparts near-equal ranges
+    const int ks0 = MODE == 1 ? (a.n_slots * kpart) / a.n_kparts : 0;
+    const int ks1 = MODE == 1 ? (a.n_slots * (kpart + 1)) / a.n_kparts : a.n_slots;
+    const int my_rounds = (ks1 - ks0 + ENC_SLOTS_PER_ROUND - 1) / ENC_SLOTS_PER_ROUND;
+    for (int rnd_i = 0; MODE < 2 && rnd_i < my_rounds; ++rnd_i) {
         // rounds are visited in a per-workgroup rotated order (same reason as kp_rot)
-        const int rnd = (int)((rnd_i + blockIdx.x) % (unsigned)a.n_rounds);
-        const int s_first = rnd * ENC_SLOTS_PER_ROUND;
-        const int s_last = min(s_first + ENC_SLOTS_PER_ROUND, a.n_slots);
+        const int rnd = (int)((rnd_i + blockIdx.x) % (unsigned)my_rounds);
+        const int s_first = ks0 + rnd * ENC_SLOTS_PER_ROUND;
+        const int s_last = min(s_first + ENC_SLOTS_PER_ROUND, ks1);
         const int kp0 = a.slot_base[s_first];
         const int kp1 = a.slot_base[s_last];
         __syncthreads();   // previous round's fragment reads are done
@@ -372,34 +390,64 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     }
 
     if (MODE == 1) {
-        // the part's slice of h1 = sin(30 * (acc + b)) (location_encoder.py:119, 147-150) to HBM
+        // this workgroup's raw partial sums of the first layer to HBM (plane kpart of a.h1)
         if (NWT != NW && wave >= NW) return;
+        const int64_t rows = ((a.B + 15) / 16) * 16;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int n = part * a.part_cols + (wave * NTW + i) * 16 + (lane & 15);
-            const double bn = a.bias[0][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t q = q0 + (lane >> 4) + 4 * r;      // (rows past B are scratch rows of h1)
-                a.h1[q * a.H + n] = sin(30.0 * (acc[0][i][r] + bn));
+                a.h1[((int64_t)kpart * rows + q) * a.H + n] = acc[0][i][r];
             }
         }
         return;
     }
-    if (MODE == 2) {
-        // the activated first layer of this tile, written by the MODE 1 workgroups
+    const int l0 = MODE == 2 ? a.rest_from : 0;   // first layer whose activation is already in LDS
+    if (MODE == 2 && l0 == 1) {
+        // the activated second layer of this tile, written by the MODE 3 workgroups
         for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
             const int q = idx / a.H, k = idx - q * a.H;
-            lds[act_addr(q, k)] = a.h1[(q0 + q) * a.H + k];
+            lds[act_addr(q, k)] = a.h2[(q0 + q) * a.H + k];
         }
+    } else if (MODE == 2 || MODE == 3) {
+        // first layer of this tile: the K parts summed in a fixed order, then
+        // h1 = sin(30 * (sum + b)) (location_encoder.py:119, 147-150)
+        const int64_t rows = ((a.B + 15) / 16) * 16;
+        for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
+            const int q = idx / a.H, k = idx - q * a.H;
+            double v = a.h1[(q0 + q) * a.H + k];
+            for (int kp = 1; kp < a.n_kparts; ++kp) v += a.h1[((int64_t)kp * rows + q0 + q) * a.H + k];
+            lds[act_addr(q, k)] = sin(30.0 * (v + a.bias[0][k]));
+        }
+    }
+    if (MODE == 3) {
+        // the part's columns of the second layer: h2 = sin(acc + b) (location_encoder.py:147-150, w0 = 1)
+        __syncthreads();
+        const int kpH3 = a.H >> 3;
+        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[1]) +
+                          ((int64_t)(part * (a.part2_cols >> 4) + wave * NTW) * kpH3) * 64 + lane;
+        gemm_kpairs<NTW, QT>(lds, wp, kpH3, kpH3, (int)((blockIdx.x * 7u) % (unsigned)kpH3), lane, acc);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int n = part * a.part2_cols + (wave * NTW + i) * 16 + (lane & 15);
+            const double bn = a.bias[1][n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t q = q0 + (lane >> 4) + 4 * r;      // (rows past B are scratch rows of h2)
+                a.h2[q * a.H + n] = sin(acc[0][i][r] + bn);
+            }
+        }
+        return;
     }
 
     // ---- hidden layers: h = sin(w0 * (acc + b)), w0 = 30 on the first layer only
     //      (location_encoder.py:83, 119, 147-150)
     const int kpH = a.H >> 3;
-    for (int layer = 0; layer < a.n_layers; ++layer) {
+    for (int layer = l0; layer < a.n_layers; ++layer) {
         __syncthreads();   // all waves finished reading the previous operand
-        if (!(MODE == 2 && layer == 0))
+        if (!(MODE == 2 && layer == l0))
             store_act<NTW, QT>(lds, a.bias[layer], layer == 0 ? 30.0 : 1.0, wave, lane, acc);
         __syncthreads();
         if (layer + 1 < a.n_layers) {
@@ -491,8 +539,19 @@ constexpr int ENC_PART_WAVES = 16;     // 4 per SIMD: the generator waits on tab
 template <int NTP, int NWP>
 __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_l1_part_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tile = blockIdx.x / a.n_parts, part = blockIdx.x - tile * a.n_parts;
-    encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a, (int64_t)tile * 16, smem, part);
+    // consecutive workgroups share a tile (its queries) and then a column part (its weights)
+    const int per_tile = a.n_parts * a.n_kparts;
+    const int tile = blockIdx.x / per_tile, rest = blockIdx.x - tile * per_tile;
+    const int part = rest / a.n_kparts, kpart = rest - part * a.n_kparts;
+    encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a, (int64_t)tile * 16, smem, part, kpart);
+}
+
+// second layer per (16-query tile, column part): NTP = the part's width / 64, one n-tile per wave
+template <int NTP>
+__global__ __launch_bounds__(NTP * 256, 1) void encoder_l2_part_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x / a.n_parts2, part = blockIdx.x - tile * a.n_parts2;
+    encoder_body<NTP, 4 * NTP, 1, 3>(a, (int64_t)tile * 16, smem, part);
 }
 
 template <int NT, int NW>

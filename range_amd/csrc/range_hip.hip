@@ -77,13 +77,14 @@ struct range_ctx {
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
     bool warned_no_keep = false;
     bool enc_split = true;    // RANGE_ENC_SPLIT=0: small batches use the one-kernel encoder too
+    bool enc_split2 = true;   // RANGE_ENC_SPLIT2=0: ... without the second layer's own split
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<float> ws_cand_dmax;
     DevBuf<int32_t> ws_exact_count;   // queries range_topk_stream recomputed by brute force
     int topks_groups = RANGE_TOPKS_GROUPS;   // RANGE_TOPKS_GROUPS in the environment overrides
     bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
-    DevBuf<double> ws_ehat64, ws_h1;
+    DevBuf<double> ws_ehat64, ws_h1, ws_h2;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
@@ -136,12 +137,13 @@ int set_dyn_lds(K kernel, size_t bytes) {
 // a workgroup streams - is split over S column parts per tile on S times as many workgroups
 // (encoder_l1_part_kernel), the rest follows per tile (encoder_rest_kernel).  One workgroup's
 // serial chain over all weights takes 0.28 ms whatever the batch; this pair takes about half.
-int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
+int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) {
     const int tiles = (int)((a.B + 15) / 16);
-    if (c->ws_h1.ensure((size_t)tiles * 16 * a.H) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
+    if (c->ws_h1.ensure((size_t)KP * tiles * 16 * a.H) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
     a.h1 = c->ws_h1.p;
     a.n_parts = S;
     a.part_cols = a.H / S;
+    a.n_kparts = KP;
     a.n_wg32 = 0;
     const size_t lds = c->enc_lds_bytes;
     const int ntp = a.part_cols / 64;
@@ -151,16 +153,50 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
     case NTP:                                                                                  \
         rc = set_dyn_lds(encoder_l1_part_kernel<NTP, NWP>, lds);                               \
         if (rc) return rc;                                                                     \
-        hipLaunchKernelGGL((encoder_l1_part_kernel<NTP, NWP>), dim3(tiles * S), dim3(ENC_PART_WAVES * 64), lds, s, a); \
+        hipLaunchKernelGGL((encoder_l1_part_kernel<NTP, NWP>), dim3(tiles * S * KP), dim3(ENC_PART_WAVES * 64), lds, s, a); \
         break;
     switch (ntp) {
         RANGE_ENC_PART(1, 4)
         RANGE_ENC_PART(2, 8)
         RANGE_ENC_PART(4, 8)
+        RANGE_ENC_PART(8, 16)
         default: return fail(RANGE_ERR_INVALID, "internal: encoder part width %d", a.part_cols);
     }
 #undef RANGE_ENC_PART
     HIP_TRY(hipGetLastError());
+    // the second layer over S2 column parts per tile where there are CUs for it (and a second
+    // hidden layer exists); the last kernel then starts from its output.  Every part re-reads the
+    // tile's partial sums and re-activates them, and a third launch costs its ~10 us: measured
+    // (tools/encoder_latency.py, RANGE_ENC_SPLIT2=0 for A/B) 16 queries 106 -> 121 us, 256 queries
+    // equal, 625 queries 127 -> 118, 1 250 queries 145 -> 135, 2 048 queries 170 -> 162 us: from 32
+    // tiles on.
+    a.rest_from = 0;
+    int S2 = 1;
+    for (int s2 = 2; s2 <= 8 && tiles >= 32 && tiles * s2 <= c->n_cu && a.n_layers >= 2; s2 *= 2) {
+        const int part = a.H / s2;
+        if (a.H % s2 == 0 && (part == 64 || part == 128 || part == 256)) S2 = s2;
+    }
+    if (S2 > 1 && c->enc_split2) {
+        if (c->ws_h2.ensure((size_t)tiles * 16 * a.H) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
+        a.h2 = c->ws_h2.p;
+        a.n_parts2 = S2;
+        a.part2_cols = a.H / S2;
+        a.rest_from = 1;
+#define RANGE_ENC_PART2(NTP)                                                                   \
+    case NTP:                                                                                  \
+        rc = set_dyn_lds(encoder_l2_part_kernel<NTP>, lds);                                    \
+        if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL((encoder_l2_part_kernel<NTP>), dim3(tiles * S2), dim3(NTP * 256), lds, s, a); \
+        break;
+        switch (a.part2_cols / 64) {
+            RANGE_ENC_PART2(1)
+            RANGE_ENC_PART2(2)
+            RANGE_ENC_PART2(4)
+            default: return fail(RANGE_ERR_INVALID, "internal: encoder part width %d", a.part2_cols);
+        }
+#undef RANGE_ENC_PART2
+        HIP_TRY(hipGetLastError());
+    }
 #define RANGE_ENC_REST(NT, NW)                                                                 \
     case NT:                                                                                   \
         rc = set_dyn_lds(encoder_rest_kernel<NT, NW>, lds);                                    \
@@ -168,6 +204,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
         hipLaunchKernelGGL((encoder_rest_kernel<NT, NW>), dim3(tiles), dim3(NW * 64), lds, s, a); \
         break;
     switch (a.H / 64) {
+        RANGE_ENC_REST(1, 4)
         RANGE_ENC_REST(2, 4)
         RANGE_ENC_REST(4, RANGE_ENC_WAVES)
         RANGE_ENC_REST(6, 4)
@@ -182,15 +219,21 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, hipStream_t s) {
 int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     EncArgs a = a_in;
     {
-        // parts per tile: a power of two that divides H/64, keeps every part >= 64 columns and
-        // gives every workgroup its own CU
+        // Workgroups per tile = column parts S (a power of two, parts of 64 .. 512 columns: the
+        // widths a kernel exists for) x K parts KP (ranges of at least 3 of the first layer's slots).
+        // Every workgroup gets its own CU; K parts come first - a column part re-generates all the
+        // features of its K range, a K part generates only its share.
         const int64_t tiles = (a.B + 15) / 16;
-        int S = 1;
-        for (int s2 = 2; s2 <= 8 && tiles * s2 <= c->n_cu; s2 *= 2) {
-            const int part = a.H / s2;
-            if (a.H % s2 == 0 && (part == 64 || part == 128 || part == 256)) S = s2;   // parts a kernel exists for
-        }
-        if (S > 1 && c->enc_split) return launch_encoder_split(c, a, S, s);
+        int S = 1, KP = 1;
+        const int kp_max = std::max(1, std::min(7, a.n_slots / 3));
+        for (int kp = 1; kp <= kp_max; ++kp)
+            for (int s2 = 1; s2 <= 8; s2 *= 2) {
+                const int part = a.H / s2;
+                if (a.H % s2 || !(part == 64 || part == 128 || part == 256 || part == 512)) continue;
+                if (tiles * s2 * kp > c->n_cu) continue;
+                if (s2 * kp > S * KP || (s2 * kp == S * KP && kp > KP)) { S = s2; KP = kp; }
+            }
+        if (S * KP > 1 && c->enc_split) return launch_encoder_split(c, a, S, KP, s);
     }
     // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
     // them would be less than half full, it is run with 16-query workgroups instead (about half
@@ -329,6 +372,7 @@ int range_create(int device, range_ctx** out) {
     c->allow_keep = !(keep && keep[0] == '0');
     if (const char* e = std::getenv("RANGE_HOST_TIMING")) c->host_timing = e[0] == '1';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT")) c->enc_split = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     *out = c;

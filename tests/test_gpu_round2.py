@@ -53,7 +53,8 @@ def test_forward_host_equals_device_result(B):
                                              (10, 64, 2, "closed-form"), (33, 320, 2, "analytic"), (7, 192, 1, "analytic"),
                                              (40, 384, 2, "analytic")])
 def test_small_batch_encoder_split_matches_one_kernel(L, H, layers, mode, monkeypatch):
-    """Batches of up to 2048 queries run the encoder as (first layer per column part) + (rest):
+    """Batches of up to 2048 queries run the encoder as (first layer per column part and K range) +
+    [second layer per column part, from 32 tiles on] + (rest):
     same embeddings as the one-kernel encoder to float64 summation-order noise, for every width
     the split exists for (and unchanged behaviour for those it does not), in both SH evaluations."""
     w, ws, bs = _weights(L, H, layers, 11)
@@ -65,7 +66,7 @@ def test_small_batch_encoder_split_matches_one_kernel(L, H, layers, mode, monkey
         two = _native.HipEngine("cuda:0")
         for e in (one, two):
             e.set_encoder(L, H, layers, 256, sh, ws, bs, sh_table=table)
-        for B in (1, 15, 16, 17, 250, 1024, 2048, 2049, 3000):
+        for B in (1, 15, 16, 17, 250, 600, 1024, 2048, 2049, 3000):
             x = torch.from_numpy(synth.make_queries(B, seed=B + L, lat_max=90.0)).cuda()
             a64, a32, axq = one.encode(x)
             b64, b32, bxq = two.encode(x)
