@@ -288,7 +288,11 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
                 cur = nxt;
             }
             // LDS-DMA of this step: the piece PVB_AHEAD steps ahead (this wave's quarter), then S / X
+#ifdef RANGE_EXP_PVB_SAMESRC   // (timing experiment: every piece from the same, cache-resident source)
+            const char* vsrc = vplanes + (int64_t)(st & 7) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
+#else
             const char* vsrc = vplanes + ((int64_t)g0 * PVB_NP + min(st + PVB_AHEAD, n_steps - 1)) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
+#endif
             const uint32_t vdst = vring_lds + vs2 * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
 #pragma unroll
             for (int ct = 0; ct < PVB_TP - 1; ++ct) {
