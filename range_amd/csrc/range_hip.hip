@@ -84,6 +84,9 @@ struct range_ctx {
     DevBuf<int32_t> ws_exact_count;   // queries range_topk_stream recomputed by brute force
     int topks_groups = RANGE_TOPKS_GROUPS;   // RANGE_TOPKS_GROUPS in the environment overrides
     bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
+    bool topks_bf16 = true;                  // RANGE_TOPKS_KEYS=f32: stream the float32 keys (no prefilter)
+    DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
+    float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     DevBuf<double> ws_ehat64, ws_h1, ws_h2;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
@@ -375,6 +378,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
+    if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
     *out = c;
     return RANGE_OK;
 }
@@ -502,6 +506,22 @@ int range_set_bank(range_ctx* c, const float* keys, const float* values, const f
     HIP_TRY(hipMemcpy(c->d_keys.p, keys, (size_t)n_rows * KEY_DIM * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_values.p, values, (size_t)n_rows * VAL_DIM * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy2D(c->d_xyz4.p, 16, xyz, 12, 12, (size_t)n_rows, hipMemcpyHostToDevice));
+    {   // bf16 copy of the keys for the prefilter of range_topk_stream, and the largest row norm
+        const int64_t n_tiles = n_pad / BLK;
+        HIP_TRY(c->d_keys_bf16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
+        const int64_t threads = n_tiles * 8 * 64;
+        hipLaunchKernelGGL(keyfrag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, c->d_keys.p,
+                           n_pad, n_tiles, reinterpret_cast<ts_u32x4*>(c->d_keys_bf16.p));
+        HIP_TRY(hipGetLastError());
+        double n2max = 0.0;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            double n2 = 0.0;
+            const float* kr = keys + r * KEY_DIM;
+            for (int e = 0; e < KEY_DIM; ++e) n2 += (double)kr[e] * kr[e];
+            n2max = std::max(n2max, n2);
+        }
+        c->key_norm_max = (float)(std::sqrt(n2max) * 1.000001);
+    }
     HIP_TRY(hipDeviceSynchronize());
     c->n_rows = n_rows;
     c->n_pad = n_pad;
@@ -749,6 +769,10 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     // the time of 1.3.
     constexpr int LIST = RANGE_TOPKS_LIST;
     constexpr int NWV = 4, DEP = 2;
+    // (the bf16 prefilter with FOUR groups per pass was measured too: one pass for 64 queries takes
+    // 27.0 us against 28.7 us for two passes of two groups - the list work per group, not the
+    // stream, is what a pass costs by then - and needs 370 registers; not kept)
+    const bool bf16 = c->topks_bf16;
     int G = c->topks_groups;
     if (G != 1 && G != 2) G = n_groups <= 1 ? 1 : 2;
     const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + NWV - 1) / NWV));
@@ -768,6 +792,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     a.n_valid = c->n_rows;
     a.n_blocks = n_blocks;
     a.n_groups = n_groups;
+    a.keys_bf16 = c->d_keys_bf16.p;
 #ifdef RANGE_EXP_TS_STAMPS
     static DevBuf<unsigned long long> stamps_buf;
     HIP_TRY(stamps_buf.ensure((size_t)n_lists * 8));
@@ -789,11 +814,25 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         ev1 = c->get_event();
         HIP_TRY(hipEventRecord(ev0, s));
     }
+#define RANGE_TOPKS_LAUNCH_BF16(GG)                                                                 \
+    do {                                                                                            \
+        rc = set_dyn_lds(topk_stream_bf16_kernel<GG, LIST>, TOPKS_LDS_BYTES);                       \
+        if (rc) return rc;                                                                          \
+        ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);                                                 \
+        hipLaunchKernelGGL((topk_stream_bf16_kernel<GG, LIST>), dim3((unsigned)n_wg), dim3(256),    \
+                           TOPKS_LDS_BYTES, s, a);                                                  \
+    } while (0)
     for (int rep = 0; rep < std::max(1, repeats); ++rep) {
-        if (G == 1) RANGE_TOPKS_LAUNCH(1);
-        else RANGE_TOPKS_LAUNCH(2);
+        if (bf16) {
+            if (G == 1) RANGE_TOPKS_LAUNCH_BF16(1);
+            else RANGE_TOPKS_LAUNCH_BF16(2);
+        } else {
+            if (G == 1) RANGE_TOPKS_LAUNCH(1);
+            else RANGE_TOPKS_LAUNCH(2);
+        }
     }
 #undef RANGE_TOPKS_LAUNCH
+#undef RANGE_TOPKS_LAUNCH_BF16
     HIP_TRY(hipGetLastError());
     if (repeats > 1) {
         HIP_TRY(hipEventRecord(ev1, s));
@@ -859,7 +898,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         hipLaunchKernelGGL(topk_merge_kernel<LIST>, dim3((unsigned)B), dim3((unsigned)((n_lists + 63) / 64 * 64)),
                            0, s, c->ws_cand_keys.p, c->ws_cand_dmax.p, n_lists, B, (int)k, c->row_offset,
                            c->d_keys.p, ehat32, c->n_rows, c->topks_force_exact ? 1 : 0,
-                           c->ws_exact_count.p, topk_val, topk_idx);
+                           c->ws_exact_count.p, bf16 ? TSB_EPS_REL : 0.f, c->key_norm_max, topk_val, topk_idx);
     }
     HIP_TRY(hipGetLastError());
     return RANGE_OK;

@@ -41,6 +41,7 @@ struct TopkStreamArgs {
     int32_t n_blocks;
     int32_t n_groups;           // ceil(B / 16)
     unsigned long long* stamps; // RANGE_EXP_TS_STAMPS builds: 8 s_memrealtime stamps per wave
+    const void* keys_bf16;      // prefilter form: (n_tiles, 8 chunks, 64 lanes, 8) bf16, see keyfrag_kernel
 };
 
 #ifdef RANGE_EXP_TS_STAMPS   // tuning only: where a wave's time goes (100 MHz real-time counter)
@@ -344,6 +345,209 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void topk_stream_kernel(TopkStream
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefilter on bf16 keys (the default of range_topk_stream; results identical to the float32 scan).
+//
+// The float32 scan above is not waiting for HBM at 16 queries: a wave spends its time in the 64
+// float32 MFMAs per tile and per query group.  Here the scan reads a bf16 copy of the keys (half
+// the bytes) and forms APPROXIMATE similarities with 16 bf16 MFMAs per tile and group - the query
+// to 16 significant bits (two bf16 planes), the key rounded to bf16 - so
+//     |approx - exact| <= (2^-9 + 2^-17) |q| |k|   (+ 3e-5 of accumulation)  =: eps.
+// A group's query operand is 64 registers; one or two groups share a pass over the keys.
+// The lists, their dmax bookkeeping and the candidate layout are those of the float32 scan, on
+// approximate values.  topk_merge_kernel then takes every candidate within 2 eps of the k-th best
+// approximate value, recomputes ITS similarity with the float32 fmaf chain (= the MFMA chain of the
+// float32 kernels, bit for bit) and ranks those: a row of the true top k cannot be missing (its
+// approximate value is within eps of its exact one, and the k-th best approximate value within eps
+// of the k-th best exact one) unless a list dropped it - which the dmax check, widened by the same
+// 2 eps, detects and answers with the brute-force path as before.
+
+typedef __bf16 ts_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t ts_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TSB_TILE_BYTES = 8 * 1024;          // 16 rows x 256 bf16 in fragment order
+constexpr int TSB_DEPTH = 4;                      // ring slots per wave (32 KB in flight per wave, as above)
+constexpr float TSB_EPS_REL = 0.002f;             // eps / (|q| |k|): 2^-9 = 0.001953 + accumulation
+
+__device__ __forceinline__ uint32_t ts_cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// keys (n_alloc rows x 256 f32) -> bf16 A-operand fragments of v_mfma_f32_16x16x32_bf16: tile t,
+// chunk c (32 dims), lane (m, kg): the 8 values K[16 t + pi_row(m)][32 c + 8 kg + 0..7], RNE.
+// (pi_row: the row order of the float32 tiles, so that the list code sees the same rows.)
+__global__ __launch_bounds__(256) void keyfrag_kernel(const float* __restrict__ keys, int64_t n_alloc,
+                                                      int64_t n_tiles, ts_u32x4* __restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_tiles * 8 * 64) return;
+    const int lane = (int)(id & 63), c = (int)((id >> 6) & 7);
+    const int64_t t = id >> 9;
+    const int64_t row = t * 16 + pi_row(lane & 15);
+    ts_u32x4 o = {0u, 0u, 0u, 0u};
+    if (row < n_alloc) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(keys + row * KEY_DIM + 32 * c + 8 * (lane >> 4));
+        const f32x4 a = src[0], b = src[1];
+        o[0] = ts_cvt_pk_bf16(a.x, a.y); o[1] = ts_cvt_pk_bf16(a.z, a.w);
+        o[2] = ts_cvt_pk_bf16(b.x, b.y); o[3] = ts_cvt_pk_bf16(b.z, b.w);
+    }
+    out[id] = o;
+}
+
+template <int G, int L>
+__global__ __launch_bounds__(256, 1) void topk_stream_bf16_kernel(TopkStreamArgs a) {
+    static_assert(TOPKS_SG % G == 0, "groups per pass must divide the supergroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PPS = TOPKS_SG / G;
+    constexpr int DEPTH = TSB_DEPTH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem) + wave * DEPTH * TSB_TILE_BYTES;
+    const char* my = smem + wave * DEPTH * TSB_TILE_BYTES + lane * 16;
+    const int n_waves = gridDim.x * 4;
+    const int w_id = wave * gridDim.x + blockIdx.x;
+    const int T = (a.n_blocks + n_waves - 1) / n_waves;
+    const int n_pass = (a.n_groups + G - 1) / G;
+    const int n_sg = (a.n_groups + TOPKS_SG - 1) / TOPKS_SG;
+    const int total = n_pass * T;
+    const int last = a.n_blocks - 1;
+    const char* kb = reinterpret_cast<const char*>(a.keys_bf16);
+    // one tile = 8 KB, contiguous in fragment order: 8 LDS-DMA operations (two groups of four)
+    auto issue_seq = [&](int k) __attribute__((always_inline)) {
+        const int i = k < total ? k % T : T - 1;
+        const int tile = w_id + i * n_waves;
+        const char* src = kb + (int64_t)(tile < last ? tile : last) * TSB_TILE_BYTES;
+        const uint32_t dst = lds0 + (k % DEPTH) * TSB_TILE_BYTES;
+#pragma unroll
+        for (int gr = 0; gr < 2; ++gr) {
+            dma_group_begin(dst + gr * 4096);
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) dma_b128_q_nt(src + gr * 4096, (uint32_t)(lane << 4), i4);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue_seq(d);
+
+    uint32_t prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
+    const uint32_t n_valid32 = (uint32_t)a.n_valid;
+
+    int k = 0;
+    for (int sg = 0; sg < n_sg; ++sg) {
+        ShortList<L> lists[TOPKS_SG];
+#pragma unroll
+        for (int gi = 0; gi < TOPKS_SG; ++gi) lists[gi].init();
+#pragma unroll
+        for (int ps = 0; ps < PPS; ++ps) {
+            const int grp0 = (sg * PPS + ps) * G;
+            if (grp0 < a.n_groups) {
+                // B operand: lane (n = query j, kg = g) holds Q[j][32 c + 8 g + 0..7], chunk c, as
+                // two bf16 planes (q = q_h + q_m to 2^-17)
+                ts_u32x4 qh[G][8], qm[G][8];
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    const int grp = min(grp0 + gi, a.n_groups - 1);
+                    const int64_t q = (int64_t)grp * 16 + j;
+                    const f32x4* rowp =
+                        reinterpret_cast<const f32x4*>(a.ehat + (q < a.B ? q : a.B - 1) * KEY_DIM);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x4 v0 = rowp[8 * c + 2 * g], v1 = rowp[8 * c + 2 * g + 1];
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = v[2 * e], y = v[2 * e + 1];
+                            const uint32_t h = ts_cvt_pk_bf16(x, y);
+                            const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xFFFF0000u);
+                            qh[gi][c][e] = h; qm[gi][c][e] = ts_cvt_pk_bf16(rx, ry);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(qh[gi][c]), "+v"(qm[gi][c]));
+                }
+                f32x4 prev[G];
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) prev[gi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                uint32_t prev_row0 = 0;
+                auto push_prev = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t row = prev_row0 + prow[r];
+                        const float x = row < n_valid32 ? prev[gi][r] : -INFINITY;
+                        lists[ps * G + gi].push(x, row);
+                    }
+                };
+                for (int i = 0; i < T; ++i, ++k) {
+                    const int tile = w_id + i * n_waves;
+                    // tile k has landed when at most the 8 operations of each younger tile are outstanding
+                    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                    const char* kt = my + (k % DEPTH) * TSB_TILE_BYTES;
+                    ts_u32x4 kf[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const ts_u32x4*>(kt + c * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(kf[c]));
+                    issue_seq(k + DEPTH);
+                    if (tile >= a.n_blocks) continue;
+                    f32x4 acc[G];
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) {
+                        f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {      // small terms first
+                            const ts_bf16x8 kk = __builtin_bit_cast(ts_bf16x8, kf[c]);
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kk, __builtin_bit_cast(ts_bf16x8, qm[gi][c]), c0, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const ts_bf16x8 kk = __builtin_bit_cast(ts_bf16x8, kf[c]);
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kk, __builtin_bit_cast(ts_bf16x8, qh[gi][c]), c0, 0, 0, 0);
+                        }
+                        acc[gi] = c0;
+                        push_prev(gi);     // the previous tile's values, in the shadow of this chain
+                    }
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) prev[gi] = acc[gi];
+                    prev_row0 = (uint32_t)tile * BLK;
+                }
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) push_prev(gi);
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < TOPKS_SG; ++gi) {
+            const int grp = sg * TOPKS_SG + gi;
+            if (grp < a.n_groups) {
+                unsigned long long kk[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i)
+                    kk[i] = lists[gi].row[i] != 0xFFFFFFFFu ? topk_key(lists[gi].v[i], lists[gi].row[i]) : 0ull;
+                unsigned long long drop = 0ull;
+                merge4_short<L>(kk, drop);
+                float dm = lists[gi].dmax;
+                dm = fmaxf(dm, __shfl_xor(dm, 16));
+                dm = fmaxf(dm, __shfl_xor(dm, 32));
+                if (drop != 0ull) dm = fmaxf(dm, topk_key_val(drop));
+                if (g == 0) {
+                    const int64_t at = ((int64_t)grp * 16 + j) * n_waves + w_id;
+                    unsigned long long* o = a.cand + at * L;
+#pragma unroll
+                    for (int i = 0; i < L; i += 2)
+                        *reinterpret_cast<ulonglong2*>(o + i) = make_ulonglong2(kk[i], kk[i + 1]);
+                    a.dmax[at] = dm;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // One workgroup per query.  Thread p owns the sorted list (L keys) of stream wave p (<= 1024).
 //  1. a lower bound T of the query's 16th best value: inside each wave of this kernel, the 16th
 //     largest list head (rank by counting over the wave's 64 heads); T = the largest of the waves'
@@ -355,13 +559,71 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void topk_stream_kernel(TopkStream
 //     recomputed by brute force over all rows, each thread walking its rows with the SAME fmaf
 //     chain as the MFMA (k order: for s, for component, for lane group) and full 16-deep lists.
 //     exact_count (optional) counts the queries that took that path.
+//  Prefilter form (eps_rel > 0: the candidates carry APPROXIMATE values from bf16 keys, within
+//  eps = eps_rel |q| kmax of the float32 similarity): the threshold of step 1 is lowered by 2 eps,
+//  step 2 ranks the survivors by approximate value to find the k-th best approximate value v_k,
+//  step 3 widens the check to dall >= v_k - 2 eps, and then every survivor >= v_k - 2 eps gets its
+//  float32 similarity by the fmaf chain of the brute-force path (one thread per survivor, 1 KB of
+//  key row each) and the survivors are ranked again by those: the result is that of the float32 scan.
 constexpr int TOPKM_CAP = 2048;    // survivor buffer (keys)
+
+// the similarity every float32 kernel computes: acc = fmaf(K[16 s + 4 g + c], Q[16 s + 4 g + c], acc)
+// in the order s = 0..15, c = 0..3, g = 0..3 of the MFMA chain
+__device__ __forceinline__ float topk_exact_dot(const float* __restrict__ kr, const float* sh_q) {
+    float acc = 0.f;
+    for (int s = 0; s < 16; ++s) {
+        f32x4 kc[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) kc[gg] = *reinterpret_cast<const f32x4*>(kr + 16 * s + 4 * gg);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) acc = __builtin_fmaf(kc[gg][c], sh_q[16 * s + 4 * gg + c], acc);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ uint32_t topk_ordered_bits(float v) { return (uint32_t)(topk_key(v, 0u) >> 32); }
+
+// The brute-force path of topk_merge_kernel: every row's float32 similarity, full 16-deep lists,
+// wave merges through `sh` (16 x MAX_TOPK keys), result in res[0..MAX_TOPK).  Not inlined: its
+// 16-deep lists would cost the common path of the kernel (128 registers at 1024 threads) spills.
+__device__ __attribute__((noinline)) void topk_brute_force(const float* __restrict__ keys, int64_t n_valid,
+                                                           const float* sh_q, unsigned long long* sh,
+                                                           unsigned long long* res) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+    KeyList X;
+    X.init();
+    for (int64_t row = threadIdx.x; row < n_valid; row += blockDim.x)
+        X.push(topk_key(topk_exact_dot(keys + row * KEY_DIM, sh_q), (uint32_t)row));
+    merge_wave(X);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = X.k[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        KeyList M;
+        M.init();
+        if (lane < n_wv) {
+#pragma unroll
+            for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
+        }
+        merge_wave(M);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < MAX_TOPK; ++i) res[i] = M.k[i];
+        }
+    }
+    __syncthreads();
+}
 
 template <int L>
 __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long long* cand, const float* dmax,
                                                           int n_parts, int64_t B, int k, int64_t row_offset,
                                                           const float* keys, const float* ehat, int64_t n_valid,
                                                           int force_exact, int* exact_count,
+                                                          float eps_rel, float kmax,
                                                           float* oval, int64_t* oidx) {
     __shared__ unsigned long long surv[TOPKM_CAP];
     __shared__ unsigned long long sh[16 * MAX_TOPK];
@@ -388,6 +650,21 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     }
     if (threadIdx.x == 0) { sh_cnt = 0; sh_flag = 0; }
     if (threadIdx.x < MAX_TOPK) res[threadIdx.x] = 0ull;
+    // prefilter form: the query (for the float32 similarities of the survivors) and its norm
+    float eps2 = 0.f;
+    if (eps_rel > 0.f) {
+        float sq = 0.f;
+        for (int e = threadIdx.x; e < KEY_DIM; e += blockDim.x) { const float v = ehat[q * KEY_DIM + e]; sh_q[e] = v; sq += v * v; }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
+        if (lane == 0) sh_d[wave] = sq;                      // (sh_d is written again in step 1, after a barrier)
+        __syncthreads();
+        float n2 = 0.f;
+        for (int w = 0; w < n_wv; ++w) n2 += sh_d[w];
+        // (a bound, not a result: 1 % over the norm covers its rounding)
+        eps2 = 2.f * eps_rel * 1.01f * sqrtf(n2) * kmax;
+        __syncthreads();
+    }
     // ---- 1. lower bound T of the 16th best value (ordered value bits only): every wave hands in
     //      its K largest list heads (n_wv * K >= 32 values, each the head of a different list, so
     //      sixteen candidates are >= the 16th largest of them); with 1024 lists that is close to
@@ -423,6 +700,7 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     }
     float dall = -INFINITY;
     for (int w = 0; w < n_wv; ++w) dall = fmaxf(dall, sh_d[w]);
+    if (eps2 > 0.f && T != 0u) T = topk_ordered_bits(topk_key_val((unsigned long long)T << 32) - eps2);
     // ---- 2. survivors
     // (one LDS atomic per wave and list position: the lanes of a wave take consecutive places)
 #pragma unroll
@@ -452,54 +730,64 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     if (threadIdx.x == 0) {
         const unsigned long long kth = res[k - 1];
         // (nothing can have been dropped while fewer than k rows exist)
-        const bool unsafe = force_exact || S > TOPKM_CAP || (kth != 0ull && dall >= topk_key_val(kth)) ||
+        const bool unsafe = force_exact || S > TOPKM_CAP || (kth != 0ull && dall >= topk_key_val(kth) - eps2) ||
                             (kth == 0ull && dall > -INFINITY);
         sh_flag = unsafe ? 1 : 0;
         if (unsafe && exact_count) atomicAdd(exact_count, 1);
     }
     __syncthreads();
-    if (sh_flag) {
-        // brute force, bit-identical similarities: acc = fmaf(K[row][16 s + 4 g + c], Q[..], acc)
-        // in the order s = 0..15, c = 0..3, g = 0..3 of the MFMA chain (qk order of the kernels)
-        for (int e = threadIdx.x; e < KEY_DIM; e += blockDim.x) sh_q[e] = ehat[q * KEY_DIM + e];
-        __syncthreads();
-        KeyList X;
-        X.init();
-        for (int64_t row = threadIdx.x; row < n_valid; row += blockDim.x) {
-            const float* kr = keys + row * KEY_DIM;
-            float acc = 0.f;
-            for (int s = 0; s < 16; ++s) {
+    if (!sh_flag && eps2 > 0.f) {
+        // ---- 3b. prefilter form: float32 similarities of the survivors within 2 eps of the k-th
+        //      best approximate value, ranked again (keys stay unique: the row is part of the key)
+        const unsigned long long kth = res[k - 1];
+        const float vmin = kth != 0ull ? topk_key_val(kth) - eps2 : -INFINITY;
+        __syncthreads();                                     // (every thread has read res)
+        if (threadIdx.x < MAX_TOPK) res[threadIdx.x] = 0ull;
+        // 16 lanes per survivor: lane s loads chunk s of the key row (one round trip for the whole
+        // row), then the chain runs chunk by chunk in the kernels' order, its value handed from lane
+        // to lane (every lane computes on its own chunk each step; only lane `step`'s result counts)
+        {
+            const int sub = lane & 15;
+            f32x4 qc[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) qc[gg] = *reinterpret_cast<const f32x4*>(sh_q + 16 * sub + 4 * gg);
+            for (int t0 = 0; t0 < S; t0 += blockDim.x >> 4) {
+                const int t = t0 + (threadIdx.x >> 4);
+                const unsigned long long key = t < S ? surv[t] : 0ull;
+                const bool live = key != 0ull && topk_key_val(key) >= vmin;
+                const uint32_t row = live ? topk_key_row(key) : 0u;
+                const float* kr = keys + (int64_t)row * KEY_DIM + 16 * sub;
                 f32x4 kc[4];
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg) kc[gg] = *reinterpret_cast<const f32x4*>(kr + 16 * s + 4 * gg);
+                for (int gg = 0; gg < 4; ++gg) kc[gg] = *reinterpret_cast<const f32x4*>(kr + 4 * gg);
+                float acc = 0.f;
+                for (int step = 0; step < 16; ++step) {
+                    float v = acc;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) acc = __builtin_fmaf(kc[gg][c], sh_q[16 * s + 4 * gg + c], acc);
+                        for (int gg = 0; gg < 4; ++gg) v = __builtin_fmaf(kc[gg][c], qc[gg][c], v);
+                    }
+                    acc = __shfl(v, (lane & 48) | step);
                 }
-            }
-            X.push(topk_key(acc, (uint32_t)row));
-        }
-        merge_wave(X);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < MAX_TOPK; ++i) sh[wave * MAX_TOPK + i] = X.k[i];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            KeyList M;
-            M.init();
-            if (lane < n_wv) {
-#pragma unroll
-                for (int i = 0; i < MAX_TOPK; ++i) M.k[i] = sh[lane * MAX_TOPK + i];
-            }
-            merge_wave(M);
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < MAX_TOPK; ++i) res[i] = M.k[i];
+                __syncthreads();                             // (surv[t] read by all 16 lanes before it changes)
+                if (t < S && sub == 0) surv[t] = live ? topk_key(acc, row) : 0ull;
             }
         }
         __syncthreads();
+        for (int t = threadIdx.x; t < S; t += blockDim.x) {
+            const unsigned long long key = surv[t];
+            if (key == 0ull) continue;
+            int r = 0;
+            for (int u = 0; u < S; ++u) r += surv[u] > key ? 1 : 0;
+            if (r < MAX_TOPK) res[r] = key;
+        }
+        __syncthreads();
+    }
+    if (sh_flag) {
+        for (int e = threadIdx.x; e < KEY_DIM; e += blockDim.x) sh_q[e] = ehat[q * KEY_DIM + e];
+        __syncthreads();
+        topk_brute_force(keys, n_valid, sh_q, sh, res);
     }
     if (threadIdx.x < k) {
         const unsigned long long mm = res[threadIdx.x];

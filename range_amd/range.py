@@ -96,10 +96,12 @@ class LocationEncoder(nn.Module):
 
     #: queries per engine call; bounds the per-call workspace (split slabs of chunk x 4 KB)
     chunk_size = 16384
-    #: topk(): batches up to this size use the HBM-streaming kernel (about 25 us per 32 queries on
-    #: range_db_large: 108 us for 128 queries), larger ones pass 1 + a selection over its kept
-    #: logits (0.15 ms up to 128 queries, 0.19 ms at 256, 0.56 ms at 1024; tools/topk_total_time.py)
-    topk_stream_max = 160
+    #: topk(): batches up to this size go through the HBM-streaming kernel in one call (bf16-key
+    #: prefilter + float32 re-rank: 26 us for 16 queries on range_db_large, 38 us for 64, 0.11 ms for
+    #: 256, 0.80 ms for 2 048, 4.0 ms for 10 000 - faster than pass 1 + a selection over its kept
+    #: logits at every size, 0.16 ms / 1.09 ms / 4.9 ms for up to 128 / 2 048 / 10 000 queries;
+    #: tools/topk_total_time.py); larger batches in chunks of this size
+    topk_stream_max = 16384
 
     def __init__(self, args):
         super().__init__()
@@ -236,13 +238,16 @@ class LocationEncoder(nn.Module):
         if self._model_id is None:
             raise ValueError("topk() needs a bank (RANGE / RANGE+)")
         vals, idxs = [], []
-        if 0 < x.shape[0] <= self.topk_stream_max:
-            # a handful of queries: the HBM-streaming kernel (every wave streams its own key tiles)
-            _, e32, _ = self.engine.encode(x)
-            return self.engine.topk_stream(e32, k)
-        for i in range(0, x.shape[0], self.chunk_size):
-            _, e32, xq = self.engine.encode(x[i:i + self.chunk_size])
-            _, tv, ti = self.engine.scan_stats(e32, xq, float(self.args.temp), 0.0, topk=k)
+        # the HBM-streaming kernel (every wave streams its own key tiles against 16 or 32 queries
+        # per pass); the forward's own top-k (pass 1 keeps the logits anyway) is scan_stats(topk=k)
+        for i in range(0, x.shape[0], self.topk_stream_max):
+            _, e32, _ = self.engine.encode(x[i:i + self.topk_stream_max])
+            tv, ti = self.engine.topk_stream(e32, k)
             vals.append(tv)
             idxs.append(ti)
+        if len(vals) == 1:
+            return vals[0], idxs[0]
+        if not vals:
+            return (torch.empty((0, k), dtype=torch.float32, device=x.device),
+                    torch.empty((0, k), dtype=torch.int64, device=x.device))
         return torch.cat(vals), torch.cat(idxs)

@@ -123,3 +123,70 @@ def test_stream_topk_ragged_banks(N, B, k):
     assert len(bad) <= max(1, B // 50)
     if N < k:
         assert (ti[:, N:] == -1).all()
+
+
+def _topk_engines(monkeypatch, keys, vals, xyz):
+    """(engine with the default bf16-key prefilter, engine streaming the float32 keys)"""
+    pre = _native.HipEngine("cuda:0")
+    monkeypatch.setenv("RANGE_TOPKS_KEYS", "f32")
+    f32 = _native.HipEngine("cuda:0")
+    monkeypatch.delenv("RANGE_TOPKS_KEYS")
+    for e in (pre, f32):
+        e.set_bank(keys, vals, xyz)
+    return pre, f32
+
+
+def test_topk_stream_bf16_prefilter_is_exact(monkeypatch):
+    """range_topk_stream scans a bf16 copy of the keys and re-ranks the candidates within its error
+    bound with the float32 chain: values and indices must be those of the float32 scan bit for bit,
+    also where the bf16 rounding scrambles the order (a crowd of rows within 1e-4 of the k-th
+    place), for un-normalised queries and keys (the bound scales with the norms), for every k, and
+    where everything ties (fallback to the brute-force path)."""
+    rng = np.random.default_rng(21)
+    N, d = 30011, 256
+    keys = rng.standard_normal((N, d)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    q = rng.standard_normal((40, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # a crowd around the 16th place of queries 0..7: 60 rows whose similarity to query b is
+    # 0.5 + i * 2e-6 (differences far below the bf16 error of 2e-3, above float32 resolution)
+    for b in range(8):
+        rows = rng.choice(N, 60, replace=False)
+        for i, r in enumerate(rows):
+            u = rng.standard_normal(d).astype(np.float64)
+            u -= u.dot(q[b].astype(np.float64)) * q[b]
+            u /= np.linalg.norm(u)
+            s = 0.5 + i * 2e-6
+            keys[r] = (s * q[b] + np.sqrt(1 - s * s) * u).astype(np.float32)
+    vals = np.zeros((N, 1024), np.float32)
+    xyz = np.zeros((N, 3), np.float32)
+    pre, f32 = _topk_engines(monkeypatch, keys, vals, xyz)
+    for qs in (q, q[:16], q[:5], q * np.float32(3.7)):
+        for k in (16, 7, 1):
+            e = torch.from_numpy(np.ascontiguousarray(qs)).cuda()
+            av, ai = pre.topk_stream(e, k)
+            bv, bi = f32.topk_stream(e, k)
+            assert torch.equal(ai, bi) and torch.equal(av, bv)
+    assert pre.topk_stream_exact_count() == 0          # the crowd fits the candidate lists: no fallback
+    # the float32 scan itself against the float64 oracle (indices; values to float32 rounding)
+    s64 = q.astype(np.float64) @ keys.astype(np.float64).T
+    rv, ri = O.topk64(s64, 16)
+    av, ai = pre.topk_stream(torch.from_numpy(q).cuda(), 16)
+    np.testing.assert_allclose(av.cpu().numpy(), rv, rtol=0, atol=3e-7)
+    same = (ai.cpu().numpy() == ri).all(axis=1)
+    assert same[8:].all()                               # (inside the crowd float32 itself may swap neighbours 2e-6 apart)
+    # keys of other norms: rows scaled by 0.25 .. 4
+    scale = rng.uniform(0.25, 4.0, size=(N, 1)).astype(np.float32)
+    pre2, f322 = _topk_engines(monkeypatch, keys * scale, vals, xyz)
+    e = torch.from_numpy(q).cuda()
+    av, ai = pre2.topk_stream(e, 16)
+    bv, bi = f322.topk_stream(e, 16)
+    assert torch.equal(ai, bi) and torch.equal(av, bv)
+    # everything ties: 5000 copies of one row (more candidates than any list or buffer holds)
+    same_keys = np.repeat(keys[:1], 5000, axis=0)
+    pre3, f323 = _topk_engines(monkeypatch, same_keys, vals[:5000], xyz[:5000])
+    av, ai = pre3.topk_stream(e[:3], 16)
+    bv, bi = f323.topk_stream(e[:3], 16)
+    assert torch.equal(ai, bi) and torch.equal(av, bv)
+    assert ai.cpu().numpy().tolist() == [list(range(16))] * 3     # ties: lower rows first
+    assert pre3.topk_stream_exact_count() == 3

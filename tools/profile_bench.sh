@@ -20,9 +20,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- $B --step
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/pmc1 -o p -- $B --steps 3 --warmup 1 > $O/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2 -o p -- $B --steps 3 --warmup 1 > $O/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc3 -o p -- $B --steps 3 --warmup 1 > $O/p3.log 2>&1
-RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan1 -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1.log 2>&1
+RANGE_TOPKS_KEYS=f32 RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan1 -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1.log 2>&1
+RANGE_TOPKS_KEYS=f32 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scanf -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scanf.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan_pmc -o p -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan_pmc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scan -o ts -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan.log 2>&1
-RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan1_pmc -o p -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1_pmc.log 2>&1
+RANGE_TOPKS_KEYS=f32 RANGE_TOPKS_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan1_pmc -o p -- python3 $R/tools/small_batch_scan.py --stream-only > $O/scan1_pmc.log 2>&1
 # the opt-in pass 2 on bf16 planes next to the exact one: times + error vs the float64 oracle, kernel trace, fetched bytes
 python3 $R/tools/pv_modes.py --json > $O/pv_modes.json 2> $O/pv_modes.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pv -o pv -- python3 $R/tools/pv_modes.py > $O/pv.log 2>&1

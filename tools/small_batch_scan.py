@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """HBM-bound regime of the keys scan (north star: "top-k similarity scan ... HBM GB/s against the
-roofline"): tiny query batches against range_db_large.  GPU only."""
+roofline"): tiny query batches against range_db_large.  GPU only.  RANGE_TOPKS_KEYS=f32 streams the
+float32 keys instead of the default bf16 prefilter."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -41,6 +42,10 @@ for B, topk in (((16, 16), (32, 16), (64, 16)) if stream_only else
         for _ in range(50): eng.topk_stream(e32, topk)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / 50 * 1e6
+        bf16 = os.environ.get("RANGE_TOPKS_KEYS", "bf16") != "f32"    # the default: bf16 prefilter + float32 re-rank
+        sb = byt // 2 if bf16 else byt
         print(f"        B={B}: whole call {wall:6.1f} us; merge kernel {mms / mn * 1e3:5.1f} us;", end="")
-        print(f"        stream kernel: {us:8.1f} us  ({passes} key passes)  {passes*byt/us/1e6:6.2f} TB/s of keys = {100*passes*byt/us/1e6/8.0:5.1f} % of 8 TB/s")
+        print(f"        stream kernel ({'bf16' if bf16 else 'f32'} keys): {us:8.1f} us  ({passes} key passes)  "
+              f"streams {passes*sb/us/1e6:6.2f} TB/s = {100*passes*sb/us/1e6/8.0:5.1f} % of 8 TB/s"
+              f" (float32 key bytes / time: {passes*byt/us/1e6:6.2f} TB/s)")
         eng.profile_enable(False)
