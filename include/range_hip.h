@@ -178,13 +178,16 @@ int64_t range_kept_queries(const range_ctx* ctx);
 /* Small-batch top-k, the HBM-streaming form of the keys scan (no reference counterpart; north star:
  * "brute-force cosine-similarity top-k ... coalesced HBM-streaming kernel with per-wavefront
  * running top-k").  A persistent grid (one workgroup per CU): every wave streams its own 16-row
- * key tiles through a wave-private LDS ring against groups of 16 queries in registers; 1, 2 or 4
- * groups share one pass over the keys (<= 32 queries per pass is the HBM-bound regime), further
- * groups take further passes inside the same launch.  Meant for B up to about a hundred.  Same
- * outputs and tie rule as the top-k of range_scan_stats.  Per-lane candidate lists are short
- * (8 entries); a query whose lists may have dropped a top-k member (detected exactly) is
- * recomputed by brute force inside the merge kernel - range_topk_stream_exact_count reports how
- * many queries took that path since the context was created (synchronises the device). */
+ * key tiles through a wave-private LDS ring against groups of 16 queries in registers; 1 or 2
+ * groups share one pass over the keys, further groups take further passes inside the same
+ * launch.  Faster than range_scan_stats' top-k at every batch size.  Same outputs and tie rule as
+ * the top-k of range_scan_stats.  By default the scan reads a bf16 copy of the keys (built by
+ * range_set_bank) and the candidates within its error bound are re-ranked with the float32
+ * similarity: the results are those of the float32 scan bit for bit (RANGE_TOPKS_KEYS=f32 in the
+ * environment selects that one).  Per-lane candidate lists are short (4 entries); a query whose
+ * lists may have dropped a top-k member (detected exactly) is recomputed by brute force inside
+ * the merge kernel - range_topk_stream_exact_count reports how many queries took that path since
+ * the context was created (synchronises the device). */
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);
