@@ -265,7 +265,11 @@ class ShardedRange:
         one all-gather of the candidates, k-way merge."""
         W, B = self.world, lonlat.shape[0]
         _, e32_all, xq_all = self._gather_queries(lonlat)
-        _, tv, ti = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, 0.0, topk=k)
+        if hasattr(self.engine, "topk_stream"):
+            # the HBM-streaming kernel: faster than pass 1's own top-k at every batch size
+            tv, ti = self.engine.topk_stream(e32_all, k)
+        else:
+            _, tv, ti = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, 0.0, topk=k)
         # values and int64 indices travel in one buffer (index bit patterns viewed as 2 x f32)
         packed = torch.empty((W * B, k, 3), dtype=torch.float32, device=tv.device)
         packed[:, :, 0] = tv
