@@ -632,6 +632,8 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     __shared__ unsigned long long res[MAX_TOPK];
     __shared__ uint32_t sh_top[64];
     __shared__ float sh_d[16];
+    __shared__ float sh_n2[16];
+    __shared__ unsigned long long surv2[TOPKM_CAP];      // prefilter form: the survivors' float32 keys
     __shared__ float sh_q[KEY_DIM];
     __shared__ int sh_cnt, sh_flag;
     const int n_wv = blockDim.x >> 6;
@@ -653,19 +655,14 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     if (threadIdx.x == 0) { sh_cnt = 0; sh_flag = 0; }
     if (threadIdx.x < MAX_TOPK) res[threadIdx.x] = 0ull;
     // prefilter form: the query (for the float32 similarities of the survivors) and its norm
+    // (its partial sums of squares travel with step 1's barrier)
     float eps2 = 0.f;
     if (eps_rel > 0.f) {
         float sq = 0.f;
         for (int e = threadIdx.x; e < KEY_DIM; e += blockDim.x) { const float v = ehat[q * KEY_DIM + e]; sh_q[e] = v; sq += v * v; }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
-        if (lane == 0) sh_d[wave] = sq;                      // (sh_d is written again in step 1, after a barrier)
-        __syncthreads();
-        float n2 = 0.f;
-        for (int w = 0; w < n_wv; ++w) n2 += sh_d[w];
-        // (a bound, not a result: 1 % over the norm covers its rounding)
-        eps2 = 2.f * eps_rel * 1.01f * sqrtf(n2) * kmax;
-        __syncthreads();
+        if (lane == 0) sh_n2[wave] = sq;
     }
     // ---- 1. lower bound T of the 16th best value (ordered value bits only): every wave hands in
     //      its K largest list heads (n_wv * K >= 32 values, each the head of a different list, so
@@ -702,6 +699,12 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
     }
     float dall = -INFINITY;
     for (int w = 0; w < n_wv; ++w) dall = fmaxf(dall, sh_d[w]);
+    if (eps_rel > 0.f) {
+        float n2 = 0.f;
+        for (int w = 0; w < n_wv; ++w) n2 += sh_n2[w];
+        // (a bound, not a result: 1 % over the norm covers its rounding)
+        eps2 = 2.f * eps_rel * 1.01f * sqrtf(n2) * kmax;
+    }
     if (eps2 > 0.f && T != 0u) T = topk_ordered_bits(topk_key_val((unsigned long long)T << 32) - eps2);
     // ---- 2. survivors
     // (one LDS atomic per wave and list position: the lanes of a wave take consecutive places)
@@ -772,16 +775,15 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const unsigned long lo
                     }
                     acc = __shfl(v, (lane & 48) | step);
                 }
-                __syncthreads();                             // (surv[t] read by all 16 lanes before it changes)
-                if (t < S && sub == 0) surv[t] = live ? topk_key(acc, row) : 0ull;
+                if (t < S && sub == 0) surv2[t] = live ? topk_key(acc, row) : 0ull;
             }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < S; t += blockDim.x) {
-            const unsigned long long key = surv[t];
+            const unsigned long long key = surv2[t];
             if (key == 0ull) continue;
             int r = 0;
-            for (int u = 0; u < S; ++u) r += surv[u] > key ? 1 : 0;
+            for (int u = 0; u < S; ++u) r += surv2[u] > key ? 1 : 0;
             if (r < MAX_TOPK) res[r] = key;
         }
         __syncthreads();
