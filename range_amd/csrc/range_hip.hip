@@ -78,6 +78,7 @@ struct range_ctx {
     bool warned_no_keep = false;
     bool enc_split = true;    // RANGE_ENC_SPLIT=0: small batches use the one-kernel encoder too
     bool enc_split2 = true;   // RANGE_ENC_SPLIT2=0: ... without the second layer's own split
+    bool enc_tail_split = true;   // RANGE_ENC_TAIL=0: the last partial round of a large batch as 16-query workgroups
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
     DevBuf<float> ws_cand_dmax;
@@ -219,6 +220,19 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     return RANGE_OK;
 }
 
+// column parts S x K parts KP of the small-batch split for `tiles` 16-query tiles (1 x 1: none)
+static void choose_encoder_split(const range_ctx* c, const EncArgs& a, int64_t tiles, int& S, int& KP) {
+    S = 1; KP = 1;
+    const int kp_max = std::max(1, std::min(7, a.n_slots / 3));
+    for (int kp = 1; kp <= kp_max; ++kp)
+        for (int s2 = 1; s2 <= 8; s2 *= 2) {
+            const int part = a.H / s2;
+            if (a.H % s2 || !(part == 64 || part == 128 || part == 256 || part == 512)) continue;
+            if (tiles * s2 * kp > c->n_cu) continue;
+            if (s2 * kp > S * KP || (s2 * kp == S * KP && kp > KP)) { S = s2; KP = kp; }
+        }
+}
+
 int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     EncArgs a = a_in;
     {
@@ -227,15 +241,8 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
         // Every workgroup gets its own CU; K parts come first - a column part re-generates all the
         // features of its K range, a K part generates only its share.
         const int64_t tiles = (a.B + 15) / 16;
-        int S = 1, KP = 1;
-        const int kp_max = std::max(1, std::min(7, a.n_slots / 3));
-        for (int kp = 1; kp <= kp_max; ++kp)
-            for (int s2 = 1; s2 <= 8; s2 *= 2) {
-                const int part = a.H / s2;
-                if (a.H % s2 || !(part == 64 || part == 128 || part == 256 || part == 512)) continue;
-                if (tiles * s2 * kp > c->n_cu) continue;
-                if (s2 * kp > S * KP || (s2 * kp == S * KP && kp > KP)) { S = s2; KP = kp; }
-            }
+        int S, KP;
+        choose_encoder_split(c, a, tiles, S, KP);
         if (S * KP > 1 && c->enc_split) return launch_encoder_split(c, a, S, KP, s);
     }
     // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
@@ -244,6 +251,28 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     const int64_t wg32 = (a.B + ENC_QTILE - 1) / ENC_QTILE;
     const int64_t full_rounds = wg32 / c->n_cu;
     const int64_t rem = a.B - full_rounds * c->n_cu * ENC_QTILE;      // queries after the full rounds
+    // A tail of up to 2 048 queries after full rounds runs as the small-batch kernels (its tiles
+    // spread over all CUs: ~0.16 ms for 1 808 queries) instead of a round of 16-query workgroups
+    // (0.23 ms whatever its fill): 10 000 queries = 256 x 32 + a split tail of 113 tiles.
+    if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split) {
+        int S, KP;
+        choose_encoder_split(c, a, (rem + 15) / 16, S, KP);
+        if (S * KP > 1) {
+            const int64_t b_main = a.B - rem;
+            EncArgs m = a;
+            m.B = b_main;
+            int rc = launch_encoder(c, m, s);          // (whole rounds of 32-query workgroups)
+            if (rc) return rc;
+            EncArgs t = a;
+            t.B = rem;
+            t.lonlat = a.lonlat + 2 * b_main;
+            t.ehat64 = a.ehat64 + ENC_EMBED * b_main;
+            t.eraw64 = a.eraw64 ? a.eraw64 + ENC_EMBED * b_main : nullptr;
+            t.ehat32 = a.ehat32 + ENC_EMBED * b_main;
+            t.xq = a.xq + 4 * b_main;
+            return launch_encoder_split(c, t, S, KP, s);
+        }
+    }
     int grid;
     if (a.B <= (int64_t)16 * c->n_cu) {
         // a batch that fits in one round either way: half-size workgroups on twice the CUs
@@ -376,6 +405,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_HOST_TIMING")) c->host_timing = e[0] == '1';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT")) c->enc_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_TAIL")) c->enc_tail_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
