@@ -43,11 +43,12 @@ def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 class ShardedRange:
     """RANGE / RANGE+ forward over a row-sharded bank.  ``engine`` holds THIS rank's rows."""
 
-    #: scanned queries (all ranks' rows of a chunk) below which a forward is not split further:
-    #: a chunk's pass 2 must still fill the chip (64 query tiles x the bank splits); measured on
-    #: one GPU in the shape of an 8-rank strong-scaling step (tools/shard_emulate.py --chunks):
-    #: two chunks of 5 000 scanned queries cost nothing, and hide half of the partials' exchange
-    min_chunk = 4096
+    #: queries per rank and chunk below which a forward is not split further.  A chunk's exchange
+    #: hides behind the next chunk's pass 2, but splitting pass 2 costs too (two launches of 5 000
+    #: scanned queries against a 12 500-row shard: 2 x 0.986 ms instead of 1.913 ms): worth it
+    #: where a rank ships >= 8 MB to each peer (2 ranks in the strong mode, any count in the weak
+    #: mode), a wash at 4 and 8 ranks in the strong mode (tools/shard_emulate.py --chunks)
+    min_chunk = 2048
 
     def __init__(self, engine, model_name: str = "RANGE+", beta: Optional[float] = 0.5,
                  group=None, n_chunks: Optional[int] = None):
@@ -172,7 +173,7 @@ class ShardedRange:
         query-tile size: a chunk then starts on a tile of the kept logits)."""
         W = self.world
         n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
-        n_chunks = max(1, min(n_chunks, (W * B) // self.min_chunk))
+        n_chunks = max(1, min(n_chunks, B // self.min_chunk))
         cuts = sorted({min(B, ((B * c) // n_chunks + 32) // 64 * 64) for c in range(1, n_chunks)})
         bounds = [0] + [c for c in cuts if 0 < c < B] + [B]
         return list(zip(bounds[:-1], bounds[1:]))

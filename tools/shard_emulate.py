@@ -42,8 +42,8 @@ for mode in ("strong", "weak"):
         x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
         e64, e32, xq = eng.encode(x)
         e32_all, xq_all = e32.repeat(W, 1).contiguous(), xq.repeat(W, 1).contiguous()
-        # ShardedRange._chunk_bounds: up to 4 chunks of at least 4096 scanned queries (--chunks k forces k)
-        n_chunks = max(1, min(4, (W * B) // 4096)) if W > 1 else 1
+        # ShardedRange._chunk_bounds: up to 4 chunks of at least 2048 queries per rank (--chunks k forces k)
+        n_chunks = max(1, min(4, B // 2048)) if W > 1 else 1
         if FORCE_CHUNKS:
             n_chunks = FORCE_CHUNKS
         cuts = [0] + [((B * c) // n_chunks + 32) // 64 * 64 for c in range(1, n_chunks)] + [B]
