@@ -4,9 +4,11 @@
 // the 64-queries-per-workgroup decomposition of pass 1 wastes the machine.  Here the grid is
 // PERSISTENT (one workgroup per CU, launched once): every WAVE streams its own 16-row key tiles
 // through a wave-private LDS ring of two tiles filled by LDS-DMA - no workgroup barrier in the
-// loop - against G groups of 16 queries held in registers (G = 1, 2 or 4 groups share one pass
+// loop - against G groups of 16 queries held in registers (G = 1 or 2 groups share one pass
 // over the keys), and several passes run back to back in the one launch with the ring kept full
-// across the pass boundary.
+// across the pass boundary.  (This file holds two forms of the scan: the float32 one described
+// here, and the bf16-key prefilter built on it - further down - which is what range_topk_stream
+// runs by default.)
 //
 // What makes the stream the only thing that takes time:
 //  * the K fragments of a tile are read into registers at once (16 ds_read_b128), so the ring
@@ -15,12 +17,12 @@
 //  * the MFMAs are compiler builtins here (no 256-accumulator register pressure as in pass 2), so
 //    hipcc pads their hazards and interleaves the list maintenance of the PREVIOUS tile's values
 //    into the MFMA shadow of the current one (software pipeline of depth one);
-//  * the per-lane candidate lists are SHORT (L = 8 values per lane and group instead of 16): a
+//  * the per-lane candidate lists are SHORT (L = 4 values per lane and group instead of 16): a
 //    wave sees only N / 16 / n_waves tiles (6 for range_db_large), i.e. ~24 values per lane, so
 //    16-deep lists never saturate and every value costs a full insertion.  Exactness is kept by
 //    bookkeeping: every lane tracks the largest value it ever let go (dmax); the final merge
 //    (topk_merge_kernel) compares the largest dmax of a query with the k-th value it found, and
-//    only if some dropped value could have belonged to the top-k - 9 of a query's best 16 rows in
+//    only if some dropped value could have belonged to the top-k - 5 of a query's best 16 rows in
 //    the few rows ONE lane sees, or exact ties - recomputes that query by brute force in the same
 //    kernel (bit-identical dot products: an MFMA chain is an fmaf chain in a fixed order).
 //
