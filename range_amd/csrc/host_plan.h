@@ -37,6 +37,24 @@ inline int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, in
     return best;
 }
 
+// Small-batch encoder: workgroups per 16-query tile = column parts S (a power of two, parts of
+// 64 .. 512 columns: the widths a kernel exists for) x K parts KP (ranges of at least 3 of the
+// first layer's slots).  Every workgroup gets its own CU (tiles * S * KP <= n_cu); K parts come
+// first - a column part re-generates all the features of its K range, a K part generates only
+// its share.  1 x 1: no split.
+inline void choose_encoder_split(int n_cu, int n_slots, int H, long long tiles, int& S, int& KP) {
+    S = 1;
+    KP = 1;
+    const int kp_max = std::max(1, std::min(7, n_slots / 3));
+    for (int kp = 1; kp <= kp_max; ++kp)
+        for (int s2 = 1; s2 <= 8; s2 *= 2) {
+            const int part = H / s2;
+            if (H % s2 || !(part == 64 || part == 128 || part == 256 || part == 512)) continue;
+            if (tiles * s2 * kp > n_cu) continue;
+            if (s2 * kp > S * KP || (s2 * kp == S * KP && kp > KP)) { S = s2; KP = kp; }
+        }
+}
+
 // The encoder's first-layer K order: the L*L spherical-harmonic features permuted into "slots"
 // (slot 0 = order 0; slot s >= 1 = orders {s, L-s}, or {s} when s == L-s), every slot padded to
 // whole k-step pairs (8 features).  perm: padded position -> feature index l*l+l+m, or -1.

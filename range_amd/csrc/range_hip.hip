@@ -220,29 +220,13 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     return RANGE_OK;
 }
 
-// column parts S x K parts KP of the small-batch split for `tiles` 16-query tiles (1 x 1: none)
-static void choose_encoder_split(const range_ctx* c, const EncArgs& a, int64_t tiles, int& S, int& KP) {
-    S = 1; KP = 1;
-    const int kp_max = std::max(1, std::min(7, a.n_slots / 3));
-    for (int kp = 1; kp <= kp_max; ++kp)
-        for (int s2 = 1; s2 <= 8; s2 *= 2) {
-            const int part = a.H / s2;
-            if (a.H % s2 || !(part == 64 || part == 128 || part == 256 || part == 512)) continue;
-            if (tiles * s2 * kp > c->n_cu) continue;
-            if (s2 * kp > S * KP || (s2 * kp == S * KP && kp > KP)) { S = s2; KP = kp; }
-        }
-}
-
 int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     EncArgs a = a_in;
     {
-        // Workgroups per tile = column parts S (a power of two, parts of 64 .. 512 columns: the
-        // widths a kernel exists for) x K parts KP (ranges of at least 3 of the first layer's slots).
-        // Every workgroup gets its own CU; K parts come first - a column part re-generates all the
-        // features of its K range, a K part generates only its share.
+        // small batches: the first layer split over column parts and K ranges (host_plan.h)
         const int64_t tiles = (a.B + 15) / 16;
         int S, KP;
-        choose_encoder_split(c, a, tiles, S, KP);
+        choose_encoder_split(c->n_cu, a.n_slots, a.H, tiles, S, KP);
         if (S * KP > 1 && c->enc_split) return launch_encoder_split(c, a, S, KP, s);
     }
     // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
@@ -256,7 +240,7 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     // (0.23 ms whatever its fill): 10 000 queries = 256 x 32 + a split tail of 113 tiles.
     if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split) {
         int S, KP;
-        choose_encoder_split(c, a, (rem + 15) / 16, S, KP);
+        choose_encoder_split(c->n_cu, a.n_slots, a.H, (rem + 15) / 16, S, KP);
         if (S * KP > 1) {
             const int64_t b_main = a.B - rem;
             EncArgs m = a;

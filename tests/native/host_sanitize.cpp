@@ -75,6 +75,27 @@ static void test_choose_splits() {
     CHECK(choose_splits(157, 6250, 256, 1, 32, 0.0014) == 13);   // the bench geometry
 }
 
+static void test_encoder_split() {
+    for (int H : {64, 128, 192, 256, 320, 384, 512})
+        for (int n_slots : {1, 2, 4, 6, 9, 21})
+            for (long long tiles : {1LL, 2LL, 16LL, 40LL, 79LL, 113LL, 128LL, 129LL, 157LL, 1000LL}) {
+                int S = -1, KP = -1;
+                choose_encoder_split(256, n_slots, H, tiles, S, KP);
+                CHECK(S >= 1 && KP >= 1 && (S * KP == 1 || tiles * S * KP <= 256));
+                CHECK(KP == 1 || n_slots / KP >= 3 || KP <= n_slots / 3);
+                if (S * KP > 1) CHECK(H % S == 0 && (H / S == 64 || H / S == 128 || H / S == 256 || H / S == 512));
+            }
+    int S, KP;
+    choose_encoder_split(256, 21, 512, 79, S, KP);   // a 1 250-query rank of an 8-GPU strong-scaling step
+    CHECK(S == 1 && KP == 3);
+    choose_encoder_split(256, 21, 512, 1, S, KP);    // one tile
+    CHECK(S * KP == 56 && KP == 7);
+    choose_encoder_split(256, 21, 512, 157, S, KP);  // more tiles than half the CUs: no split
+    CHECK(S == 1 && KP == 1);
+    choose_encoder_split(256, 21, 384, 10, S, KP);   // a width without part kernels
+    CHECK(S == 1 && KP == 1);
+}
+
 static void test_copy_pool() {
     std::mt19937_64 rng(11);
     for (int threads : {1, 3, 8}) {
@@ -97,6 +118,7 @@ static void test_copy_pool() {
 int main() {
     test_plan_and_packing();
     test_choose_splits();
+    test_encoder_split();
     test_copy_pool();
     std::puts("host_sanitize ok");
     return 0;
