@@ -15,17 +15,23 @@
 //   group R = bank rows 32R .. 32R+31 (one MFMA K step), piece P = 256 output columns,
 //   column tile ct (16 columns), plane p, lane (n, g), 8 bf16:
 //   byte address ((((R*4 + P)*16 + ct)*3 + p)*64 + lane)*16
-// so a piece (48 KB) is one contiguous LDS-DMA copy and a B operand one conflict-free
-// ds_read_b128.  Element i of lane (n, g) is row 32R + (i < 4 ? pi_row(4g+i) : 16 + pi_row(4g+i-4))
-// - the order in which a lane of pass 1 holds its logits (attend_kernels.h: pi_row) - and column
-// 64*(t>>2) + 4n + (t&3) of tile t = 16P + ct (the accumulator order of attend_stored_kernel, so
-// the two kernels share their epilogue layout).  The weights come straight from the lane's own
-// kept logits: no lane exchange, no LDS round trip for the A operand.
+// so a B operand is one coalesced 1 KB load per wave.  Element i of lane (n, g) is row
+// 32R + (i < 4 ? pi_row(4g+i) : 16 + pi_row(4g+i-4)) - the order in which a lane of pass 1 holds
+// its logits (attend_kernels.h: pi_row) - and column 64*(t>>2) + 4n + (t&3) of tile t = 16P + ct.
+// The weights come straight from the lane's own kept logits.
 //
-// Work decomposition as in attend_stored_kernel: workgroup = 4 waves = 64 queries, wave w owns
-// queries 16w..16w+15 and all 1024 output columns (64 accumulator tiles = 256 AGPRs); the four
-// waves share every piece of V through a 3-slot LDS ring (144 KB: 96 KB in flight per CU while
-// the third slot is read).  One step = one piece = 16 column tiles x (3 operand reads + 6 MFMAs).
+// Work decomposition: workgroup = 4 waves = 64 queries; wave w owns the 256 COLUMNS of piece w for
+// all 64 queries: 4 query tiles x 16 column tiles = 64 accumulator tiles = 256 AGPRs.  A B fragment
+// is used by exactly one wave, so it goes from global memory straight to that wave's registers (a
+// ring of 8 column tiles = 24 KB per wave in flight) - no LDS staging of V - and only the A
+// operands cross waves: each wave forms the weights of its own 16 queries and publishes the three
+// planes (3 KB) through a double-buffered LDS area that all four waves read at the start of a
+// group, behind the one barrier per 32 rows.
+//
+// History: the first version kept attend_stored_kernel's decomposition - wave =
+// 16 queries x 1024 columns, V pieces through a 3-slot LDS ring by LDS-DMA - and ran in 8.8 ms:
+// every wave read every piece from LDS (128 B/clk of operand reads next to the DMA writes); with
+// a quarter of those reads (timing experiment) it took 7.0 ms.  This tiling: 7.9 ms.
 #pragma once
 #include "attend_kernels.h"
 
@@ -34,23 +40,8 @@ namespace range_hip {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// column tiles per LDS piece: 16 (3 ring slots of 48 KB, 96 KB in flight) or 8 (6 slots of 24 KB,
-// 120 KB in flight, twice the barriers: measured 9.04 ms against 8.70 - the stream is not waiting
-// for latency, more bytes in flight do not help)
-#ifndef RANGE_PVB_TILES
-#define RANGE_PVB_TILES 16
-#endif
-constexpr int PVB_TP = RANGE_PVB_TILES;
-static_assert(PVB_TP == 16 || PVB_TP == 8, "piece of 16 or 8 column tiles");
-constexpr int PVB_NP = 64 / PVB_TP;                            // pieces (= steps) per 32-row group
-constexpr int PVB_PIECE_BYTES = PVB_TP * 3 * 1024;             // column tiles x 3 planes x 1 KB
-constexpr int PVB_SLOTS = 144 * 1024 / PVB_PIECE_BYTES;        // V ring slots
-constexpr int PVB_AHEAD = PVB_SLOTS - 1;                       // a piece is requested this many steps ahead
-constexpr int PVB_OPS = PVB_TP * 3 / 4;                        // LDS-DMA operations per wave and piece
-constexpr int PVB_WAVE_BYTES = PVB_PIECE_BYTES / 4;            // a wave's share of a piece
-constexpr int PVB_GROUP_BYTES = 64 * 3 * 1024;                 // 32 rows x 1024 columns x 6 B
-// LDS map (bytes): V ring 144 KB | S ring 3 x 4 KB | X ring 3 x 256 B = 160,512 B
-constexpr int PVB_LDS_BYTES = PVB_SLOTS * PVB_PIECE_BYTES + 3 * 4096 + 3 * 256;
+constexpr int PVB_PIECE_BYTES = 16 * 3 * 1024;                 // 16 column tiles x 3 planes x 1 KB: a wave's share of a group
+constexpr int PVB_GROUP_BYTES = 4 * PVB_PIECE_BYTES;           // 32 rows x 1024 columns x 6 B
 
 // round-to-nearest-even float32 -> bf16 of two values, packed (lo = a, hi = b)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
@@ -124,42 +115,17 @@ __device__ __forceinline__ void mfma_bf16_a(f32x4& acc, const u32x4& a, const u3
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 #endif
 }
-// the six kept cross products of one column tile, small terms first; hook(i) runs in the gap
-// behind MFMA i (pinned there: hipcc would otherwise sink the pieces behind the whole group)
-template <class Hook>
-__device__ __forceinline__ void pvb_tile(f32x4& acc, const PvbA& a, const PvbB& b, Hook&& hook) {
-#define RANGE_PVB_MFMA(x, y, i)                      \
-    mfma_bf16_a(acc, x, y);                          \
-    __builtin_amdgcn_sched_barrier(0);               \
-    hook(i);                                         \
-    __builtin_amdgcn_sched_barrier(0)
-    RANGE_PVB_MFMA(a.l, b.h, 0);
-    RANGE_PVB_MFMA(a.m, b.m, 1);
-    RANGE_PVB_MFMA(a.h, b.l, 2);
-    RANGE_PVB_MFMA(a.m, b.h, 3);
-    RANGE_PVB_MFMA(a.h, b.m, 4);
-    RANGE_PVB_MFMA(a.h, b.h, 5);
-#undef RANGE_PVB_MFMA
-}
-__device__ __forceinline__ PvbB pvb_read(const char* vslot, int ct) {
-    PvbB b;
-    b.h = *reinterpret_cast<const u32x4*>(vslot + (ct * 3 + 0) * 1024);
-    b.m = *reinterpret_cast<const u32x4*>(vslot + (ct * 3 + 1) * 1024);
-    b.l = *reinterpret_cast<const u32x4*>(vslot + (ct * 3 + 2) * 1024);
-    return b;
-}
+#ifndef RANGE_PVB_PF
+#define RANGE_PVB_PF 8
+#endif
+constexpr int PVB2_PF = RANGE_PVB_PF;                        // ring slots of B per wave (a power of two <= 8)
+constexpr int PVB2_D = PVB2_PF - 1;                          // column tiles of B in flight per wave
+constexpr int PVB2_LDS_BYTES = 2 * 4 * 3 * 1024;             // A planes: 2 buffers x 4 query tiles x 3 planes
 
 template <bool GEO>
 __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const char* __restrict__ vplanes,
-                                                               int32_t n_groups) {
+                                                                 int32_t n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
-    const uint32_t vring_lds = lds0;
-    const uint32_t sring_lds = lds0 + PVB_SLOTS * PVB_PIECE_BYTES;
-    const uint32_t xring_lds = sring_lds + 3 * 4096;
-    const char* sring_b = smem + PVB_SLOTS * PVB_PIECE_BYTES;
-    const char* xring_b = sring_b + 3 * 4096;
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
@@ -168,11 +134,9 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
     const int g0 = (int)(((int64_t)split * n_groups) / a.n_splits);
     const int g1 = (int)(((int64_t)(split + 1) * n_groups) / a.n_splits);
     const int nG = g1 - g0;
-    const int n_steps = PVB_NP * nG;
     const int64_t q = (int64_t)qt * QTILE + wave * 16 + (lane & 15);
     const int64_t qtile_kept = (int64_t)qt + a.qt_offset;
 
-    // per-query constants: w = ca * 2^(k_sem*s - m1) + cb * 2^(k_geo*g - m2)
     float ca, cb, m1, m2, fxq;
     {
         const int64_t qq = q < a.B ? q : a.B - 1;
@@ -182,47 +146,57 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
         cb = GEO ? (1.0f - a.beta) / st.w : 0.f;
         fxq = a.xq[qq * 4 + g];
     }
+    // (ordinary loads: put hipcc's wait for them in front of the loop, see pin_qfrag)
     asm volatile("" : "+v"(ca), "+v"(cb), "+v"(m1), "+v"(m2), "+v"(fxq));
-
-    f32x4 acc[64];
+    f32x4 acc[64];                 // [query tile m][column tile ct] at 16 m + ct
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t s_rd = (uint32_t)(wave * 1024 + lane * 16);                  // this lane's logits
-    const uint32_t x_rd = (uint32_t)((pi_row(lane & 15) * 4 + g) * 4);          // as KAddr::x
     int prow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[r] = pi_row(4 * g + r);
-    const uint32_t vvoff = (uint32_t)(lane << 4);
-    const int b_first = 2 * g0, b_last = a.n_blocks - 1;
+    const int b_last = a.n_blocks - 1;
+    const int xrow = pi_row(lane & 15) * 4 + g;
 
-    // S tile (this wave's 1 KB of kept logits) + X tile of bank block b_first + bb into ring slot
-    // bb % 3: 2 vector-memory operations per wave
-    auto issue_sx = [&](int bb) __attribute__((always_inline)) {
-        const int b = min(b_first + bb, b_last);
-        const int slot = bb % 3;
-        dma_b128(a.logits + logit_tile(qtile_kept, a.n_blocks, b, wave), vvoff,
-                 sring_lds + slot * 4096 + wave * 1024);
-        dma_b32(a.xyz4 + (int64_t)b * BLK * 4, (uint32_t)(lane << 2), xring_lds + slot * 256);
+    // this wave's B operands: piece `wave` of every group, 48 KB contiguous, tile ct plane p at
+    // (ct*3+p) KB + 16 B per lane
+    // (addresses: scalar base + the lane's constant byte offset - no vector ALU work per load, which
+    // hipcc would place right behind an MFMA, into that MFMA's dying operand registers)
+    const char* vb = vplanes + ((int64_t)g0 * 4 + wave) * PVB_PIECE_BYTES;
+    const uint32_t voff16 = (uint32_t)(lane * 16), voffx = (uint32_t)(xrow * 4);
+    // Every vector-memory load of the loop is an asm statement with a hand-counted wait in front of
+    // its first use: hipcc's own counting does not follow a register ring across the loop's back
+    // edge - it waited for ALL loads of the previous group at the top of every group (8.07 ms).
+    // The loaded registers are touched by nothing but the asm MFMAs / the weights code behind
+    // their wait.  Loads retire in issue order: vmcnt(N) = "all but the N youngest are done".
+    // (the destination is written by the asm statements themselves: a returned temporary would be
+    // COPIED into the ring by the compiler, i.e. read before the load has landed)
+    // (s_nop 4: a vector-memory instruction must not read an SGPR the scalar ALU wrote less than
+    // five wait states ago, and hipcc does not see the instruction inside an asm statement)
+    auto load_b1 = [&](int gi, int ct, int plane, u32x4& dst) __attribute__((always_inline)) {
+        const char* p = vb + (int64_t)min(gi, nG - 1) * PVB_GROUP_BYTES + ct * 3072 + plane * 1024;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff16), "s"(p));
     };
-    // this wave's quarter of the piece of step st into ring slot vslot: op `i` of PVB_OPS
-    auto issue_v = [&](int st, int vslot, int i) __attribute__((always_inline)) {
-        const int sc = min(st, n_steps - 1);
-        const char* src = vplanes + ((int64_t)g0 * PVB_NP + sc) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES + (i >> 2) * 4096;
-        if ((i & 3) == 0) dma_group_begin(vring_lds + vslot * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES + (i >> 2) * 4096);
-        dma_b128_q(src, vvoff, i & 3);
+    auto load_b = [&](int gi, int ct, PvbB& b) __attribute__((always_inline)) {
+        load_b1(gi, ct, 0, b.h);
+        load_b1(gi, ct, 1, b.m);
+        load_b1(gi, ct, 2, b.l);
     };
-    // weights of bank block b_first + bb (4 per lane) -> packed bf16 planes, two words each
-    auto weights = [&](int bb, uint32_t (&h)[2], uint32_t (&m)[2], uint32_t (&l)[2]) __attribute__((always_inline)) {
-        const int slot = bb % 3;
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(sring_b + slot * 4096 + s_rd);
+    // kept logits (this wave's tile) and xyz of bank block b (two loads, also when there is no geo head:
+    // the counts below do not depend on it)
+    auto load_sx = [&](int b, f32x4& sv, float& xa) __attribute__((always_inline)) {
+        const float* ps = a.logits + logit_tile(qtile_kept, a.n_blocks, min(b, b_last), wave);
+        const float* px = a.xyz4 + (int64_t)min(b, b_last) * BLK * 4;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(sv) : "v"(voff16), "s"(ps));
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(xa) : "v"(voffx), "s"(px));
+    };
+    // weights of one block from its logits -> two packed words per plane
+    auto weights = [&](int b, const f32x4& sv, float xa, uint32_t (&h)[2], uint32_t (&m)[2], uint32_t (&l)[2]) __attribute__((always_inline)) {
         f32x4 cg = {0.f, 0.f, 0.f, 0.f};
         if (GEO) {
-            const float xa = *reinterpret_cast<const float*>(xring_b + slot * 256 + x_rd);
             mfma_v_first(cg, xa, fxq);
             asm volatile("s_nop 15" : "+v"(cg));
         }
-        const int n_left = (int)(a.n_valid - (int64_t)(b_first + bb) * BLK);
+        const int n_left = (int)(a.n_valid - (int64_t)b * BLK);
         float w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -233,133 +207,129 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
         split3(w[0], w[1], h[0], m[0], l[0]);
         split3(w[2], w[3], h[1], m[1], l[1]);
     };
+    // publish two words (one bank block) of this wave's planes of a group - the A operand of query
+    // tile `wave` - into exchange buffer bf: words 2*half, 2*half+1 of each plane
+    auto publish = [&](int bf, int half, const uint32_t (&h)[2], const uint32_t (&m)[2], const uint32_t (&l)[2]) __attribute__((always_inline)) {
+        char* o = smem + ((bf * 4 + wave) * 3) * 1024 + lane * 16 + half * 8;
+        *reinterpret_cast<uint2*>(o) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(o + 1024) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(o + 2048) = make_uint2(l[0], l[1]);
+    };
 
-    PvbA cur, nxt;
-    cur.h = cur.m = cur.l = nxt.h = nxt.m = nxt.l = u32x4{0u, 0u, 0u, 0u};
     if (nG > 0) {
-        issue_sx(0);
-        issue_sx(1);
-        issue_sx(2);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // blocks 0 and 1 have landed
+        // group 0's weights
+        const int b0 = 2 * g0;
         uint32_t h[2], m[2], l[2];
-        weights(0, h, m, l);
-        cur.h[0] = h[0]; cur.h[1] = h[1]; cur.m[0] = m[0]; cur.m[1] = m[1]; cur.l[0] = l[0]; cur.l[1] = l[1];
-        weights(1, h, m, l);
-        cur.h[2] = h[0]; cur.h[3] = h[1]; cur.m[2] = m[0]; cur.m[3] = m[1]; cur.l[2] = l[0]; cur.l[3] = l[1];
-        // slot 0 is refilled next: this wave's S tile has been read (lgkmcnt), and the X tile - one
-        // copy shared by the four waves, each of which writes it - by every wave (barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        nxt = cur;
-        // the first PVB_AHEAD pieces, with S / X of block 3 where the steady state has it relative to
-        // the pieces (the waits of the first steps count the same operations as all later ones)
-        if (PVB_NP == 4) issue_sx(3);
-#pragma unroll
-        for (int pc = 0; pc < PVB_AHEAD; ++pc) {
-#pragma unroll
-            for (int i = 0; i < PVB_OPS; ++i) issue_v(pc, pc, i);
-            if (PVB_NP == 8 && pc == 0) issue_sx(3);
-        }
+        f32x4 sv;
+        float xa;
+        load_sx(b0, sv, xa);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv), "+v"(xa));
+        weights(b0, sv, xa, h, m, l);
+        publish(0, 0, h, m, l);
+        load_sx(b0 + 1, sv, xa);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv), "+v"(xa));
+        weights(b0 + 1, sv, xa, h, m, l);
+        publish(0, 1, h, m, l);
     }
+    // B ring of PVB2_PF slots: a tile is requested PVB2_D = PVB2_PF - 1 tiles ahead, into the slot
+    // of the tile just consumed.  The first PVB2_D column tiles of group 0:
+    PvbB bq[PVB2_PF];
+#pragma unroll
+    for (int i = 0; i < PVB2_D; ++i) load_b(0, i, bq[i]);
+    bq[PVB2_D].h = bq[PVB2_D].m = bq[PVB2_D].l = u32x4{0u, 0u, 0u, 0u};
 
-    int vs = 0;                                   // ring slot of the current step
-    // The last column tile of a step is not executed in its step but carried (operands in
-    // registers) behind the next step's barrier, where it covers the latency of that step's first
-    // LDS reads.  (Before the first step the carried operands are zero.)
-    PvbB carry;
-    carry.h = carry.m = carry.l = u32x4{0u, 0u, 0u, 0u};
-    auto nohook = [](int) __attribute__((always_inline)) {};
     for (int gi = 0; gi < nG; ++gi) {
+        __syncthreads();                                     // every wave's planes of group gi are published
+        PvbA am[4];
 #pragma unroll
-        for (int P = 0; P < PVB_NP; ++P) {
-            const int st = PVB_NP * gi + P;
-            const int vs2 = vs == 0 ? PVB_SLOTS - 1 : vs - 1;       // slot of step st + PVB_AHEAD == that of st - 1
-            // The piece of this step has landed when only the operations issued during the last
-            // PVB_AHEAD - 1 steps are outstanding.  16-tile pieces: those of the previous step, 12 (V)
-            // after steps 1 and 3, 14 (V + S + X) after steps 0 and 2; 8-tile pieces: four steps of
-            // 6, one of them with S + X.
-            if (PVB_NP == 8) RANGE_WAIT_BARRIER(26);
-            else if (P & 1) RANGE_WAIT_BARRIER(14);
-            else RANGE_WAIT_BARRIER(12);
-            const char* vslot = smem + vs * PVB_PIECE_BYTES + lane * 16;
-            PvbB b0 = pvb_read(vslot, 0), b1 = pvb_read(vslot, 1);
-            pvb_tile(acc[PVB_TP * ((P + PVB_NP - 1) % PVB_NP) + PVB_TP - 1], cur, carry, nohook);
-            if (P == 0) {                                     // (in the first group nxt == cur)
-                asm volatile("s_nop 1");                      // the carried MFMAs still read cur
-                cur = nxt;
-            }
-            // LDS-DMA of this step: the piece PVB_AHEAD steps ahead (this wave's quarter), then S / X
-#ifdef RANGE_EXP_PVB_SAMESRC   // (timing experiment: every piece from the same, cache-resident source)
-            const char* vsrc = vplanes + (int64_t)(st & 7) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
-#else
-            const char* vsrc = vplanes + ((int64_t)g0 * PVB_NP + min(st + PVB_AHEAD, n_steps - 1)) * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
-#endif
-            const uint32_t vdst = vring_lds + vs2 * PVB_PIECE_BYTES + wave * PVB_WAVE_BYTES;
+        for (int mq = 0; mq < 4; ++mq) {
+            const char* o = smem + (((gi & 1) * 4 + mq) * 3) * 1024 + lane * 16;
+            am[mq].h = *reinterpret_cast<const u32x4*>(o);
+            am[mq].m = *reinterpret_cast<const u32x4*>(o + 1024);
+            am[mq].l = *reinterpret_cast<const u32x4*>(o + 2048);
+        }
+        // the next group's logits and xyz, one block at a time, five column tiles before their use
+        const int bn = 2 * (g0 + gi + 1);
+        f32x4 sv;
+        float xa;
+        load_sx(bn, sv, xa);
 #pragma unroll
-            for (int ct = 0; ct < PVB_TP - 1; ++ct) {
-                PvbB b2;
-                pvb_tile(acc[PVB_TP * P + ct], cur, b0, [&](int i) __attribute__((always_inline)) {
-                    const int cr = ct + 2 < PVB_TP ? ct + 2 : PVB_TP - 1;
-                    if (i == 0) b2.h = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 0) * 1024);
-                    else if (i == 1) b2.m = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 1) * 1024);
-                    else if (i == 2) b2.l = *reinterpret_cast<const u32x4*>(vslot + (cr * 3 + 2) * 1024);
-                    else if (i == 3) {
+        for (int ct = 0; ct < 16; ++ct) {
+            // Tile ct's three loads (requested during tile ct - PVB2_D, one behind each of its first
+            // three accumulation chains) are done when only the younger loads are outstanding: those
+            // of the PVB2_D - 1 tiles since, plus the S / X pair of this group's start if the tile was
+            // requested in the previous group (ct < PVB2_D), plus the second S / X pair (issued
+            // behind tile 5) for the tiles requested before it (6 <= ct <= PVB2_D + 5).
+            PvbB& b = bq[ct & (PVB2_PF - 1)];
+            PvbB& nb = bq[(ct + PVB2_D) & (PVB2_PF - 1)];      // the slot of tile ct - 1: free
+            constexpr int RING = 3 * (PVB2_D - 1);
+            const bool s1 = ct < PVB2_D, s2 = ct >= 6 && ct <= PVB2_D + 5;
+            if (s1 && s2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING + 4));
+            else if (s1 || s2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING + 2));
+            else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING));
+            // one chain of six per accumulator (interleaving the four query tiles term by term was
+            // slower, 8.5 ms against 8.0); one load of the tile PVB2_D ahead behind each of the first
+            // three chains (three loads back to back behind the tile measured the same, and so did a
+            // ring of 4 instead of 8 slots: the loads cost 1.2 ms of the kernel - timing experiment
+            // without them - but neither their latency nor their clustering is what costs it)
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq) {
+                f32x4& c = acc[16 * mq + ct];
+                mfma_bf16_a(c, am[mq].l, b.h);
+                mfma_bf16_a(c, am[mq].m, b.m);
+                mfma_bf16_a(c, am[mq].h, b.l);
+                mfma_bf16_a(c, am[mq].m, b.h);
+                mfma_bf16_a(c, am[mq].h, b.m);
+                mfma_bf16_a(c, am[mq].h, b.h);
 #ifndef RANGE_EXP_PVB_NODMA
-                        if (ct < PVB_OPS) {
-                            if ((ct & 3) == 0) dma_group_begin(vdst + (ct >> 2) * 4096);
-                            dma_b128_q(vsrc + (ct >> 2) * 4096, vvoff, ct & 3);
-                        } else if (ct == PVB_OPS && P % (PVB_NP / 2) == 0) {
-                            issue_sx(2 * gi + 4 + P / (PVB_NP / 2));
-                        }
+                if (mq < 3) {
+                    u32x4& dst = mq == 0 ? nb.h : mq == 1 ? nb.m : nb.l;
+                    if (ct + PVB2_D < 16) load_b1(gi, ct + PVB2_D, mq, dst);
+                    else load_b1(gi + 1, ct + PVB2_D - 16, mq, dst);
+                }
 #endif
-                    } else if (i == 5 && ct == PVB_TP - 2) {
-                        asm volatile("s_nop 1");             // the step ends: whatever follows may be vector ALU
-                    }
-                });
-                b0 = b1; b1 = b2;
             }
-            carry = b0;                                      // the step's last column tile
-            // the next group's weights: its first block after the first half of the steps, its second
-            // after the last (cut into pieces and placed in the MFMA gaps they took the same time:
-            // the vector ALU work costs its issue slots either way)
 #ifdef RANGE_EXP_PVB_NOW
             if (false) {
 #else
-            if (P % (PVB_NP / 2) == PVB_NP / 2 - 1) {
+            if (ct == 5 || ct == 11) {                       // the next group's weights, one block each time
 #endif
+                // (its S / X pair: younger are the refills of 6 tiles)
+                asm volatile("s_nop 1\n\ts_waitcnt vmcnt(18)" : "+v"(sv), "+v"(xa));
                 uint32_t h[2], m[2], l[2];
-                weights(2 * gi + 2 + P / (PVB_NP / 2), h, m, l);
-                const int o = 2 * (P / (PVB_NP / 2));
-                nxt.h[o] = h[0]; nxt.h[o + 1] = h[1];
-                nxt.m[o] = m[0]; nxt.m[o + 1] = m[1];
-                nxt.l[o] = l[0]; nxt.l[o + 1] = l[1];
+                const int half = ct == 11;
+                weights(bn + half, sv, xa, h, m, l);
+                publish((gi + 1) & 1, half, h, m, l);
+                if (!half) load_sx(bn + 1, sv, xa);
             }
-            vs = vs == PVB_SLOTS - 1 ? 0 : vs + 1;
         }
+        asm volatile("s_nop 1");
     }
-    if (nG > 0) {
-        pvb_tile(acc[63], cur, carry, nohook);
-        // hipcc knows nothing about the MFMA inside an asm statement: whatever it schedules next may
-        // read this accumulator (it moves accumulators around in front of acc_fence's operands).
-        // The wait states an MFMA result needs before a non-MFMA reader therefore sit in a
-        // statement that carries the accumulator as an operand, directly behind the last MFMA.
-        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[63]));
-    }
-    // the clamped prefetches of the last steps are still in flight into this workgroup's LDS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
+    // The clamped prefetches past the end are still in flight INTO the ring's registers: nothing
+    // else may get those registers before they have landed (hipcc would hand them to the
+    // epilogue's accumulator reads at once - the wait carries them as operands).
+#pragma unroll
+    for (int i = 0; i < PVB2_PF; ++i)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[i].h), "+v"(bq[i].m), "+v"(bq[i].l));
+    // wait states between the last MFMAs and the readers of the accumulators (see above)
+#pragma unroll
+    for (int mq = 0; mq < 4; ++mq) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[16 * mq + 15]));
     acc_fence(acc);
-    // accumulator tile 4T+c, register r, lane (j,g)  ->  out[query 4g+r of this wave][64T + 4j + c]
+    // accumulator [m][ct], register r, lane (j,g) -> out[query 16 m + 4 g + r][64 (4 wave + ct/4) + 4 j + ct%4]
     const int j = lane & 15;
-    const int64_t qw = (int64_t)qt * QTILE + wave * 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t qo = qw + 4 * g + r;
-        if (qo < a.B) {
-            float* orow = a.out + ((int64_t)split * a.B + qo) * VAL_DIM + 4 * j;
+    for (int mq = 0; mq < 4; ++mq) {
 #pragma unroll
-            for (int T = 0; T < 16; ++T) {
-                f32x4 o = {acc[4 * T + 0][r], acc[4 * T + 1][r], acc[4 * T + 2][r], acc[4 * T + 3][r]};
-                *reinterpret_cast<f32x4*>(orow + 64 * T) = o;
+        for (int r = 0; r < 4; ++r) {
+            const int64_t qo = (int64_t)qt * QTILE + 16 * mq + 4 * g + r;
+            if (qo < a.B) {
+                float* orow = a.out + ((int64_t)split * a.B + qo) * VAL_DIM + 256 * wave + 4 * j;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) {
+                    f32x4 o = {acc[16 * mq + 4 * T + 0][r], acc[16 * mq + 4 * T + 1][r],
+                               acc[16 * mq + 4 * T + 2][r], acc[16 * mq + 4 * T + 3][r]};
+                    *reinterpret_cast<f32x4*>(orow + 64 * T) = o;
+                }
             }
         }
     }

@@ -1007,13 +1007,13 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
             if (c->vplanes_groups != n_groups) return fail(RANGE_ERR_STATE, "bf16 planes of the values are missing");
             const char* planes = reinterpret_cast<const char*>(c->d_vplanes.p);
             if (geo) {
-                rc = set_dyn_lds(attend_bf16x3_kernel<true>, PVB_LDS_BYTES);
+                rc = set_dyn_lds(attend_bf16x3_kernel<true>, PVB2_LDS_BYTES);
                 if (rc) return rc;
-                hipLaunchKernelGGL(attend_bf16x3_kernel<true>, grid, block, PVB_LDS_BYTES, s, a, planes, n_groups);
+                hipLaunchKernelGGL(attend_bf16x3_kernel<true>, grid, block, PVB2_LDS_BYTES, s, a, planes, n_groups);
             } else {
-                rc = set_dyn_lds(attend_bf16x3_kernel<false>, PVB_LDS_BYTES);
+                rc = set_dyn_lds(attend_bf16x3_kernel<false>, PVB2_LDS_BYTES);
                 if (rc) return rc;
-                hipLaunchKernelGGL(attend_bf16x3_kernel<false>, grid, block, PVB_LDS_BYTES, s, a, planes, n_groups);
+                hipLaunchKernelGGL(attend_bf16x3_kernel<false>, grid, block, PVB2_LDS_BYTES, s, a, planes, n_groups);
             }
         } else if (geo) {
             rc = set_dyn_lds(attend_stored_kernel<true>, ATTEND_STORED_LDS_BYTES);
