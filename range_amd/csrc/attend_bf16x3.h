@@ -170,16 +170,26 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
     // their wait.  Loads retire in issue order: vmcnt(N) = "all but the N youngest are done".
     // (the destination is written by the asm statements themselves: a returned temporary would be
     // COPIED into the ring by the compiler, i.e. read before the load has landed)
-    // (s_nop 4: a vector-memory instruction must not read an SGPR the scalar ALU wrote less than
-    // five wait states ago, and hipcc does not see the instruction inside an asm statement)
-    auto load_b1 = [&](int gi, int ct, int plane, u32x4& dst) __attribute__((always_inline)) {
+    // A vector-memory instruction must not read an SGPR the scalar ALU wrote less than five wait
+    // states ago, and hipcc does not see the instruction inside an asm statement: addr_b() is
+    // called in FRONT of an accumulation chain (the empty asm makes hipcc put the address into its
+    // SGPRs there), load_b1() behind it.  (`early` = false: s_nop 4 instead, prologue only.)
+    auto addr_b = [&](int gi, int ct, int plane) __attribute__((always_inline)) {
         const char* p = vb + (int64_t)min(gi, nG - 1) * PVB_GROUP_BYTES + ct * 3072 + plane * 1024;
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff16), "s"(p));
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+    auto load_b1 = [&](const char* p, u32x4& dst) __attribute__((always_inline)) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff16), "s"(p));
     };
     auto load_b = [&](int gi, int ct, PvbB& b) __attribute__((always_inline)) {
-        load_b1(gi, ct, 0, b.h);
-        load_b1(gi, ct, 1, b.m);
-        load_b1(gi, ct, 2, b.l);
+        const char* p0 = addr_b(gi, ct, 0);
+        const char* p1 = addr_b(gi, ct, 1);
+        const char* p2 = addr_b(gi, ct, 2);
+        asm volatile("s_nop 4");
+        load_b1(p0, b.h);
+        load_b1(p1, b.m);
+        load_b1(p2, b.l);
     };
     // kept logits (this wave's tile) and xyz of bank block b (two loads, also when there is no geo head:
     // the counts below do not depend on it)
@@ -248,25 +258,60 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
             am[mq].m = *reinterpret_cast<const u32x4*>(o + 1024);
             am[mq].l = *reinterpret_cast<const u32x4*>(o + 2048);
         }
-        // the next group's logits and xyz, one block at a time, five column tiles before their use
+        // the next group's logits and xyz (two blocks): four loads here, used from column tile 4 on
         const int bn = 2 * (g0 + gi + 1);
-        f32x4 sv;
-        float xa;
-        load_sx(bn, sv, xa);
+        f32x4 svA, svB;
+        float xaA, xaB;
+        load_sx(bn, svA, xaA);
+        load_sx(bn + 1, svB, xaB);
+        // The weights of the next group are formed in the gaps between the accumulation chains, two
+        // statements per gap (wop below): block A during column tiles 4-9, block B during 10-15.
+        f32x4 cg = {0.f, 0.f, 0.f, 0.f};
+        float e1[4], e2[4], ww[4], ra = 0.f, rb = 0.f;
+        uint32_t hh[2] = {0u, 0u}, mm[2] = {0u, 0u}, ll[2] = {0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e1[r] = e2[r] = ww[r] = 0.f;
+        auto wop = [&](int half, int k) __attribute__((always_inline)) {
+#ifndef RANGE_EXP_PVB_NOW
+            const f32x4& sv = half ? svB : svA;
+            const float xa = half ? xaB : xaA;
+            const int n_left = (int)(a.n_valid - (int64_t)(bn + half) * BLK);
+            if (k == 0) { if (GEO) mfma_v_first(cg, xa, fxq); }
+            else if (k >= 1 && k < 5) e1[k - 1] = fmaf(sv[k - 1], a.k_sem, -m1);
+            else if (k >= 5 && k < 9) e1[k - 5] = __builtin_amdgcn_exp2f(e1[k - 5]);
+            else if (k >= 10 && k < 14) { if (GEO) e2[k - 10] = fmaf(cg[k - 10], a.k_geo, -m2); }
+            else if (k >= 14 && k < 18) { if (GEO) e2[k - 14] = __builtin_amdgcn_exp2f(e2[k - 14]); }
+            else if (k >= 18 && k < 22) ww[k - 18] = ca * e1[k - 18];
+            else if (k >= 22 && k < 26) { if (GEO) ww[k - 22] = fmaf(cb, e2[k - 22], ww[k - 22]); }
+            else if (k == 26) {
+                if (n_left < BLK) {              // pad rows exist only in the bank's last block
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ww[r] = prow[r] < n_left ? ww[r] : 0.f;
+                }
+            }
+            else if (k == 27 || k == 34) hh[k == 34] = cvt_pk_bf16(ww[2 * (k == 34)], ww[2 * (k == 34) + 1]);
+            else if (k == 28 || k == 35) ra = ww[2 * (k == 35)] - __uint_as_float(hh[k == 35] << 16);
+            else if (k == 29 || k == 36) rb = ww[2 * (k == 36) + 1] - __uint_as_float(hh[k == 36] & 0xFFFF0000u);
+            else if (k == 30 || k == 37) mm[k == 37] = cvt_pk_bf16(ra, rb);
+            else if (k == 31 || k == 38) ra = ra - __uint_as_float(mm[k == 38] << 16);
+            else if (k == 32 || k == 39) rb = rb - __uint_as_float(mm[k == 39] & 0xFFFF0000u);
+            else if (k == 33 || k == 40) ll[k == 40] = cvt_pk_bf16(ra, rb);
+            else if (k == 41) publish((gi + 1) & 1, half, hh, mm, ll);
+#endif
+        };
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             // Tile ct's three loads (requested during tile ct - PVB2_D, one behind each of its first
             // three accumulation chains) are done when only the younger loads are outstanding: those
-            // of the PVB2_D - 1 tiles since, plus the S / X pair of this group's start if the tile was
-            // requested in the previous group (ct < PVB2_D), plus the second S / X pair (issued
-            // behind tile 5) for the tiles requested before it (6 <= ct <= PVB2_D + 5).
+            // of the PVB2_D - 1 tiles since, plus the four S / X loads of this group's start if the
+            // tile was requested in the previous group (ct < PVB2_D).
             PvbB& b = bq[ct & (PVB2_PF - 1)];
             PvbB& nb = bq[(ct + PVB2_D) & (PVB2_PF - 1)];      // the slot of tile ct - 1: free
             constexpr int RING = 3 * (PVB2_D - 1);
-            const bool s1 = ct < PVB2_D, s2 = ct >= 6 && ct <= PVB2_D + 5;
-            if (s1 && s2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING + 4));
-            else if (s1 || s2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING + 2));
+            if (ct < PVB2_D) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING + 4));
             else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.h), "+v"(b.m), "+v"(b.l) : "n"(RING));
+            // the S / X loads of this group's start: younger are the loads of column tiles 0-3
+            if (ct == 4) asm volatile("s_waitcnt vmcnt(12)" : "+v"(svA), "+v"(xaA), "+v"(svB), "+v"(xaB));
             // one chain of six per accumulator (interleaving the four query tiles term by term was
             // slower, 8.5 ms against 8.0); one load of the tile PVB2_D ahead behind each of the first
             // three chains (three loads back to back behind the tile measured the same, and so did a
@@ -275,6 +320,10 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
 #pragma unroll
             for (int mq = 0; mq < 4; ++mq) {
                 f32x4& c = acc[16 * mq + ct];
+#ifndef RANGE_EXP_PVB_NODMA
+                const char* pn = nullptr;
+                if (mq < 3) pn = ct + PVB2_D < 16 ? addr_b(gi, ct + PVB2_D, mq) : addr_b(gi + 1, ct + PVB2_D - 16, mq);
+#endif
                 mfma_bf16_a(c, am[mq].l, b.h);
                 mfma_bf16_a(c, am[mq].m, b.m);
                 mfma_bf16_a(c, am[mq].h, b.l);
@@ -282,25 +331,18 @@ __global__ __launch_bounds__(256, 1) void attend_bf16x3_kernel(ScanArgs a, const
                 mfma_bf16_a(c, am[mq].h, b.m);
                 mfma_bf16_a(c, am[mq].h, b.h);
 #ifndef RANGE_EXP_PVB_NODMA
-                if (mq < 3) {
-                    u32x4& dst = mq == 0 ? nb.h : mq == 1 ? nb.m : nb.l;
-                    if (ct + PVB2_D < 16) load_b1(gi, ct + PVB2_D, mq, dst);
-                    else load_b1(gi + 1, ct + PVB2_D - 16, mq, dst);
-                }
-#endif
-            }
-#ifdef RANGE_EXP_PVB_NOW
-            if (false) {
+                if (mq < 3) load_b1(pn, mq == 0 ? nb.h : mq == 1 ? nb.m : nb.l);
+                else asm volatile("s_nop 0");                 // (no vector ALU directly behind an MFMA)
 #else
-            if (ct == 5 || ct == 11) {                       // the next group's weights, one block each time
+                asm volatile("s_nop 0");
 #endif
-                // (its S / X pair: younger are the refills of 6 tiles)
-                asm volatile("s_nop 1\n\ts_waitcnt vmcnt(18)" : "+v"(sv), "+v"(xa));
-                uint32_t h[2], m[2], l[2];
-                const int half = ct == 11;
-                weights(bn + half, sv, xa, h, m, l);
-                publish((gi + 1) & 1, half, h, m, l);
-                if (!half) load_sx(bn + 1, sv, xa);
+                if (ct >= 4) {                               // two statements of the next group's weights
+                    const int half = ct >= 10, k = 8 * (ct - (half ? 10 : 4)) + 2 * mq;
+                    __builtin_amdgcn_sched_barrier(0);
+                    wop(half, k);
+                    wop(half, k + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         asm volatile("s_nop 1");
