@@ -6,7 +6,7 @@ holds bank rows [r*N/W, (r+1)*N/W) and serves its own B queries; the soft-attent
 decomposes exactly over row shards:
 
     1. encode the local queries (kernel A)                       no communication
-    2. all-gather the query operands e32 (B,256) and xq (B,4)     W*B*1040 B per rank, tiny
+    2. ONE all-gather of the packed query operands e32 (B,256) | xq (B,4): W*B*1040 B per rank
     3. pass 1 on the local shard for ALL W*B queries -> softmax statistics (m, l) with the
        constant shift m = tau*log2(e) (unit-vector logits), so the l of disjoint shards ADD
     4. all-reduce(sum) of the l columns (W*B,2)                   8 B per query
@@ -148,22 +148,30 @@ class ShardedRange:
         return stats_local
 
     def _gather_queries(self, lonlat: torch.Tensor):
+        """Encode the own queries and gather every rank's scan operands: e32 (B,256) and xq (B,4)
+        travel as ONE packed (B,260) buffer - at these sizes a collective costs its latency, not
+        its bytes.  Returns e64 (own) and the (W*B,256) / (W*B,4) column views of the gathered
+        buffer (strided: ``_chunk_major`` lays them out for the scan)."""
         e64, e32, xq = self.engine.encode(lonlat)
-        W, B = self.world, lonlat.shape[0]
-        e32_all = self._gather(e32, "e32").reshape(W * B, e32.shape[1])
-        xq_all = self._gather(xq, "xq").reshape(W * B, xq.shape[1])
-        return e64, e32_all, xq_all
+        W, B, d = self.world, lonlat.shape[0], e32.shape[1]
+        packed = self._buf("pack:q", (B, d + xq.shape[1]), e32.dtype, e32.device)
+        packed[:, :d] = e32
+        packed[:, d:] = xq
+        allq = self._gather(packed, "q").reshape(W * B, d + xq.shape[1])
+        return e64, allq[:, :d], allq[:, d:]
 
     def _chunk_major(self, t_all: torch.Tensor, chunks, name: str) -> torch.Tensor:
-        """(W*B, d) in rank-major order -> chunk-major order: rows [lo,hi) of EVERY rank's queries
-        form one chunk, ordered by owner rank - a contiguous range of the scanned batch whose
-        partial is again W equal slices, one per destination."""
+        """(W*B, d) in rank-major order (a column view of the gathered buffer) -> contiguous,
+        chunk-major order: rows [lo,hi) of EVERY rank's queries form one chunk, ordered by owner
+        rank - a contiguous range of the scanned batch whose partial is again W equal slices, one
+        per destination."""
+        out = self._buf("cm:" + name, t_all.shape, t_all.dtype, t_all.device)
         if len(chunks) == 1:
-            return t_all
+            out.copy_(t_all)
+            return out
         W = self.world
         B = t_all.shape[0] // W
-        v = t_all.reshape(W, B, -1)
-        out = self._buf("cm:" + name, t_all.shape, t_all.dtype, t_all.device)
+        v = t_all.view(W, B, -1)
         for lo, hi in chunks:
             out[W * lo:W * hi].view(W, hi - lo, -1).copy_(v[:, lo:hi])
         return out
@@ -266,6 +274,7 @@ class ShardedRange:
         one all-gather of the candidates, k-way merge."""
         W, B = self.world, lonlat.shape[0]
         _, e32_all, xq_all = self._gather_queries(lonlat)
+        e32_all, xq_all = e32_all.contiguous(), xq_all.contiguous()
         if hasattr(self.engine, "topk_stream"):
             # the HBM-streaming kernel: faster than pass 1's own top-k at every batch size
             tv, ti = self.engine.topk_stream(e32_all, k)
