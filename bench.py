@@ -500,72 +500,73 @@ def opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev):
 
 def scan_roofline(eng, synth, torch, dev, N, bank):
     """The HBM-bound regime of the path: the keys-only top-k scan (``range_topk_stream``) for a
-    handful of queries.  The product path streams a bf16 copy of the keys (N x 512 B per pass),
-    forms approximate similarities and re-ranks the candidates inside its error bound with the
-    float32 chain - the result is that of the float32 scan, bit for bit (tests).  One pass serves 16
-    queries, or 32: two groups of 16 share a pass.  Two throughputs per entry:
-      achieved_TBps, frac          = ALGORITHMIC bytes (the reference's float32 key rows, passes x N
-                                     x 1 KB: SURVEY.md 8(d)) / time per launch, against 8 TB/s;
-      streamed_TBps, frac_streamed = the bytes the launch actually streams (passes x N x 512 B for
-                                     the bf16 copy) / time, against 8 TB/s.
-    Time per launch: the stream kernel launched 20 times back to back between one pair of HIP
-    events on the launch stream (event pairs around single launches are also given: they add ~5 us
-    of dispatch latency to a ~15 us kernel).  The entries with keys "f32" stream the float32 keys
-    (RANGE_TOPKS_KEYS=f32, the round-1/early-round-2 kernel, still the fallback-free reference
-    form): the last one forces one group per pass for 64 queries (4 passes in one launch) - the
-    pure streaming regime at a length where launch ramp-up no longer dominates."""
+    handful of queries, END TO END - one call = the stream kernel with the candidate merge as its
+    tail (one launch for up to 256 queries).  The product path streams a bf16 copy of the keys
+    (N x 512 B per pass), forms approximate similarities and re-ranks the candidates inside its error
+    bound with the float32 chain - the result is that of the float32 scan, bit for bit (tests).  One
+    pass serves 16 queries, or 32: two groups of 16 share a pass.
+
+      frac = bytes the call STREAMS (passes x N x 512 B for the bf16 copy, x 1 KB for float32 keys)
+             / time per call / 8 TB/s - never above 1; ``reference_format_TBps`` (the reference's
+             float32 key bytes / time) is given beside it and is not a roofline fraction.
+      time per call: 20 calls enqueued back to back between ONE pair of HIP events on the launch
+             stream, mean of 3 such measurements.
+
+    Two banks: this run's bank (range_db_large, N = 100 000: its 51 MB bf16 copy stays in the 256 MB
+    Infinity Cache between back-to-back calls - ``resident: infinity_cache``) and a keys-only bank
+    of N = 1 000 000 generated on the device (512 MB bf16 / 1 GB float32: every call streams it from
+    DRAM - ``resident: dram``).  ``product_path``: what ``model.topk`` runs by default."""
     from range_amd import _native
     out = []
-    extra = []
-    for nq, keys_mode, force_single in ((16, "bf16", False), (32, "bf16", False), (64, "bf16", False),
-                                        (16, "f32", False), (64, "f32", True)):
-        e = eng
-        if keys_mode == "f32" or force_single:
-            if keys_mode == "f32":
-                os.environ["RANGE_TOPKS_KEYS"] = "f32"   # read at range_create
-            if force_single:
-                os.environ["RANGE_TOPKS_GROUPS"] = "1"
-            try:
-                e = _native.HipEngine(dev)
-            finally:
-                os.environ.pop("RANGE_TOPKS_GROUPS", None)
-                os.environ.pop("RANGE_TOPKS_KEYS", None)
+
+    def big_keys(n):
+        g = torch.Generator(device=dev).manual_seed(2024)
+        k = torch.randn((n, 256), generator=g, device=dev, dtype=torch.float32)
+        c = torch.randn((32, 256), generator=g, device=dev, dtype=torch.float32)
+        k += 3.0 * c[torch.randint(0, 32, (n,), generator=g, device=dev)]
+        return torch.nn.functional.normalize(k, dim=1).contiguous()
+
+    def engine(keys_mode, keys_dev):
+        if keys_mode == "f32":
+            os.environ["RANGE_TOPKS_KEYS"] = "f32"   # read at range_create
+        try:
+            e = _native.HipEngine(dev)
+        finally:
+            os.environ.pop("RANGE_TOPKS_KEYS", None)
+        if keys_dev is None:
             e.set_bank(bank.keys, bank.values, bank.xyz, 0)
-            extra.append(e)
-        x = torch.from_numpy(synth.make_queries(nq, seed=11)).to(dev)
-        _, e32, _ = eng.encode(x)
-        for _ in range(5):
-            e.topk_stream(e32, 16)
-        e.profile_enable(True)
-        for _ in range(20):
-            e.topk_stream(e32, 16)
-        torch.cuda.synchronize(dev)
-        ms, n = e.profile_read(_native.PROF_TOPK_STREAM)
-        mms, mn = e.profile_read(_native.PROF_TOPK_MERGE)
-        e.profile_enable(False)
-        us = min(e.topk_stream_timed(e32, 16, 20)[2] for _ in range(3))
-        groups = (nq + 15) // 16
-        per_pass = 1 if (groups <= 1 or force_single) else 2    # range_topk_stream's choice (range_hip.hip)
-        passes = (groups + per_pass - 1) // per_pass
-        alg = passes * N * KEY_ROW_BYTES
-        streamed = alg // 2 if keys_mode == "bf16" else alg
-        kname = "topk_stream_bf16_kernel" if keys_mode == "bf16" else "topk_stream_kernel"
-        out.append({"kernel": f"{kname}<{per_pass} group(s) of 16 queries per pass>", "keys": keys_mode,
-                    "queries": nq, "passes": passes, "bytes": alg, "streamed_bytes": streamed, "avg_us": us,
-                    "avg_us_source": "20 back-to-back launches between one HIP event pair",
-                    "avg_us_event_pair_per_launch": ms / n * 1e3,
-                    "achieved_TBps": alg / (us * 1e-6) / 1e12,
-                    "streamed_TBps": streamed / (us * 1e-6) / 1e12, "peak_TBps": PEAK_HBM_GBS / 1e3,
-                    # the bench contract's definition: algorithmic bytes / time / peak (above 1 where
-                    # the kernel reads fewer bytes than the reference's data format holds) ...
-                    "frac": alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
-                    # ... and the share of the HBM peak the launch really uses
-                    "frac_streamed": streamed / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
-                    "product_path": keys_mode == "bf16" and not force_single,
-                    "merge_kernel_avg_us_event_pair": mms / mn * 1e3,
-                    "exact_fallback_queries": e.topk_stream_exact_count()})
-    for e in extra:
-        e.close()
+        else:
+            e.set_keys(keys_dev)
+        return e
+
+    for n_rows, resident in ((N, "infinity_cache"), (1_000_000, "dram")):
+        keys_dev = None if n_rows == N else big_keys(n_rows)
+        for keys_mode, sizes in (("bf16", (16, 32, 64)), ("f32", (16,))):
+            e = eng if (keys_mode == "bf16" and keys_dev is None) else engine(keys_mode, keys_dev)
+            for nq in sizes:
+                x = torch.from_numpy(synth.make_queries(nq, seed=11)).to(dev)
+                _, e32, _ = eng.encode(x)
+                for _ in range(5):
+                    e.topk_stream(e32, 16)
+                us = sum(e.topk_stream_timed(e32, 16, 20)[2] for _ in range(3)) / 3.0
+                groups = (nq + 15) // 16
+                per_pass = 1 if groups <= 1 else 2        # range_topk_stream's choice (range_hip.hip)
+                passes = (groups + per_pass - 1) // per_pass
+                ref_bytes = passes * n_rows * KEY_ROW_BYTES
+                streamed = ref_bytes // 2 if keys_mode == "bf16" else ref_bytes
+                kname = "topk_stream_bf16_kernel" if keys_mode == "bf16" else "topk_stream_kernel"
+                out.append({"kernel": f"{kname}<{per_pass} group(s) of 16 queries per pass> + merge tail (one launch)",
+                            "keys": keys_mode, "bank_rows": n_rows, "resident": resident, "queries": nq,
+                            "passes": passes, "streamed_bytes": streamed, "us_per_call": us,
+                            "us_source": "20 back-to-back calls between one HIP event pair, mean of 3",
+                            "streamed_TBps": streamed / (us * 1e-6) / 1e12, "peak_TBps": PEAK_HBM_GBS / 1e3,
+                            "frac": streamed / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                            "reference_format_TBps": ref_bytes / (us * 1e-6) / 1e12,
+                            "product_path": keys_mode == "bf16",
+                            "exact_fallback_queries": e.topk_stream_exact_count()})
+            if e is not eng:
+                e.close()
+        del keys_dev
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 4
+#define RANGE_ABI_VERSION 5
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -103,6 +103,13 @@ int range_set_bank(range_ctx* ctx, const float* keys, const float* values, const
                    int64_t n_rows, int64_t row_offset);
 int64_t range_bank_rows(const range_ctx* ctx);
 
+/* A keys-only bank for the top-k side channel (range_topk_stream): the satclip_embeddings column of
+ * the bank alone (range/range.py:85-89), 1 KB per row instead of 5 KB.  `keys` (n_rows x 256 float32)
+ * may be a HOST or a DEVICE pointer.  Replaces the bank of the context; every call that needs the
+ * values or the locations (range_scan_stats, range_attend*, range_forward*) then returns
+ * RANGE_ERR_STATE.  Rows need not be normalised (the top-k tolerates any norm).  Synchronous. */
+int range_set_keys(range_ctx* ctx, const float* keys, int64_t n_rows, int64_t row_offset);
+
 /* Opt-in arithmetic of the w @ V products of pass 2 (range/range.py:217, :236).  NOT in the
  * reference; the default is what the reference computes.
  *   RANGE_PV_EXACT  (default) exact float32 products (v_mfma_f32_16x16x4_f32)
@@ -150,7 +157,9 @@ int range_coord_features(range_ctx* ctx, int32_t mode, const double* lonlat_dev,
  *               utils.py:11-16) and the bank keys / xyz are (range.py:85-89, :93-95): every logit
  *               is then <= 1 and the statistics use the constant shift m = tau*log2(e) instead of
  *               a running maximum (no rescaling; partial statistics merge by plain sums).
- *               Temperatures above RANGE_MAX_TAU are rejected (2^(-2m) must stay a normal float).
+ *               Temperatures above RANGE_MAX_TAU are rejected (2^(-2m) must stay a normal float),
+ *               and so is a bank whose largest key or location row norm exceeds 1.001
+ *               (RANGE_ERR_INVALID: the constant shift would overflow).
  *   stats_dev : (B,4) float32 = {m_sem, l_sem, m_geo, l_geo}, m = tau*log2(e),
  *               l = sum 2^(tau*log2(e)*logit - m) over the rows; log-sum-exp = (m + log2 l)/log2 e.
  *               Statistics of disjoint row sets (bank splits, bank shards) of the same query
@@ -180,20 +189,27 @@ int64_t range_kept_queries(const range_ctx* ctx);
  * running top-k").  A persistent grid (one workgroup per CU): every wave streams its own 16-row
  * key tiles through a wave-private LDS ring against groups of 16 queries in registers; 1 or 2
  * groups share one pass over the keys, further groups take further passes inside the same
- * launch.  Faster than range_scan_stats' top-k at every batch size.  Same outputs and tie rule as
- * the top-k of range_scan_stats.  By default the scan reads a bf16 copy of the keys (built by
- * range_set_bank) and the candidates within its error bound are re-ranked with the float32
- * similarity: the results are those of the float32 scan bit for bit (RANGE_TOPKS_KEYS=f32 in the
- * environment selects that one).  Per-lane candidate lists are short (4 entries); a query whose
- * lists may have dropped a top-k member (detected exactly) is recomputed by brute force inside
- * the merge kernel - range_topk_stream_exact_count reports how many queries took that path since
- * the context was created (synchronises the device). */
+ * launch.  Candidate lists are merged on the way up (lane -> wave -> workgroup) and, for batches of
+ * up to one query per workgroup (256), the final merge runs as the TAIL OF THE SAME LAUNCH: the last
+ * workgroups to finish their tiles merge one query each (one launch answers the call); larger
+ * batches run the same merge as a second launch.  Faster than range_scan_stats' top-k at every
+ * batch size.  Same outputs and tie rule as the top-k of range_scan_stats.  By default the scan
+ * reads a bf16 copy of the keys (built by range_set_bank / range_set_keys) and the candidates within
+ * its error bound are re-ranked with the float32 similarity: the results are those of the float32
+ * scan bit for bit (RANGE_TOPKS_KEYS=f32 in the environment selects that one).  Per-lane candidate
+ * lists are short (4 entries); a query whose lists may have dropped a top-k member (detected
+ * exactly) is recomputed by brute force inside the merge - range_topk_stream_exact_count reports
+ * how many queries took that path since the context was created (synchronises the device; it also
+ * returns RANGE_ERR_HIP if a merging workgroup of an earlier call gave up waiting for the stream
+ * workgroups - possible only when the grid cannot be resident as a whole - in which case that
+ * call's results for its query carry index -1 / NaN). */
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);
-/* Bench harness: the same call with the stream kernel launched `repeats` (>= 2) times back to back
- * between ONE pair of HIP events on `stream` (a pair around a single ~20 us launch adds ~5 us of
- * dispatch latency to it); *avg_us = time per launch.  Synchronises with the stream. */
+/* Bench harness: the same call enqueued `repeats` (>= 2) times back to back between ONE pair of
+ * HIP events on `stream` (a pair around a single ~15 us launch adds ~5 us of dispatch latency to
+ * it); *avg_us = time per call (every launch of the call: the scan with its merge tail, or the
+ * scan and the merge launch).  Synchronises with the stream. */
 int range_topk_stream_timed(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                             float* topk_val_dev, int64_t* topk_idx_dev, int32_t repeats,
                             float* avg_us, range_stream_t stream);

@@ -36,7 +36,7 @@ SYMBOLS = (
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
-    "range_set_pv_mode", "range_get_pv_mode",
+    "range_set_pv_mode", "range_get_pv_mode", "range_set_keys",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -74,6 +74,7 @@ def load_library() -> C.CDLL:
     lib.range_set_encoder.argtypes = [vp, C.POINTER(EncoderDesc), C.POINTER(vp), C.POINTER(vp)]
     lib.range_set_sh_table.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.range_set_bank.argtypes = [vp, vp, vp, vp, i64, i64]
+    lib.range_set_keys.argtypes = [vp, vp, i64, i64]
     lib.range_bank_rows.argtypes = [vp]
     lib.range_bank_rows.restype = i64
     lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -103,7 +104,7 @@ def load_library() -> C.CDLL:
     lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 4:
+    if lib.range_abi_version() != 5:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
     flags = lib.range_build_flags().decode()
     if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":
@@ -197,6 +198,25 @@ class HipEngine:
             raise ValueError(f"bank shapes {keys.shape} {values.shape} {xyz.shape}")
         _check(self.lib, self.lib.range_set_bank(self._h, keys.ctypes.data, values.ctypes.data,
                                                  xyz.ctypes.data, n, row_offset))
+        self.n_rows = n
+        self.row_offset = row_offset
+
+    def set_keys(self, keys, row_offset: int = 0) -> None:
+        """A keys-only bank for ``topk_stream`` (range_set_keys): ``keys`` (n,256) float32, a host
+        ndarray or a tensor on this engine's GPU.  Forward / attend calls then raise."""
+        if torch.is_tensor(keys):
+            if keys.is_cuda:
+                self._t(keys, torch.float32, (KEY_DIM,))
+                n, ptr = keys.shape[0], keys.data_ptr()
+                torch.cuda.current_stream(self.device).synchronize()   # (the library copies on the null stream)
+            else:
+                keys = keys.numpy()
+        if not torch.is_tensor(keys):
+            keys = np.ascontiguousarray(keys, dtype=np.float32)
+            if keys.ndim != 2 or keys.shape[1] != KEY_DIM:
+                raise ValueError(f"keys shape {keys.shape}")
+            n, ptr = keys.shape[0], keys.ctypes.data
+        _check(self.lib, self.lib.range_set_keys(self._h, ptr, n, row_offset))
         self.n_rows = n
         self.row_offset = row_offset
 

@@ -86,8 +86,12 @@ struct range_ctx {
     int topks_groups = RANGE_TOPKS_GROUPS;   // RANGE_TOPKS_GROUPS in the environment overrides
     bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
     bool topks_bf16 = true;                  // RANGE_TOPKS_KEYS=f32: stream the float32 keys (no prefilter)
+    bool topks_fused = true;                 // RANGE_TOPKS_FUSED=0: the merge as a second launch at every batch size (A/B)
+    DevBuf<uint32_t> ws_topk_sync;           // TOPKS_SYNC_WORDS: arrival counters, done, sticky error, key-norm scratch
+    bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
+    float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
     DevBuf<double> ws_ehat64, ws_h1, ws_h2;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
@@ -314,8 +318,19 @@ int build_vplanes(range_ctx* c) {
 int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* xq, int64_t B,
                    float tau_sem, float tau_geo, bool pass1, int p1_max_splits = 128) {
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
+    if (!c->has_values)
+        return fail(RANGE_ERR_STATE, "keys-only bank (range_set_keys): only range_topk_stream runs on it");
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
     if (!(tau_sem > 0.f)) return fail(RANGE_ERR_INVALID, "tau_sem must be > 0");
+    // the constant shift m = tau * log2(e) of the softmax statistics needs every logit <= 1:
+    // unit keys (range/range.py:85-89).  A bank that skipped that preparation would overflow.
+    if (c->key_norm_max > 1.001f)
+        return fail(RANGE_ERR_INVALID, "bank keys are not L2-normalised (largest row norm %.4f): the softmax of "
+                    "range_scan_stats / range_attend needs unit keys, as range/range.py:85-89 prepares them "
+                    "(range_topk_stream accepts any norm)", (double)c->key_norm_max);
+    if (tau_geo > 0.f && c->xyz_norm_max > 1.001f)
+        return fail(RANGE_ERR_INVALID, "bank locations are not unit vectors (largest row norm %.4f): the geographic "
+                    "softmax needs them as range/utils/utils.py:11-16 computes them", (double)c->xyz_norm_max);
     // the softmax statistics use the constant shift m = tau * log2(e) (scan_stats_kernel): the
     // smallest term 2^(-2m) must stay a normal float32
     if (tau_sem > RANGE_MAX_TAU || tau_geo > RANGE_MAX_TAU)
@@ -393,6 +408,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
+    if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
     *out = c;
     return RANGE_OK;
 }
@@ -492,12 +508,42 @@ int range_set_sh_table(range_ctx* c, int32_t L, const double* front, const doubl
     const size_t lds = c->enc_lds_base + (size_t)ENC_QTILE * L * sizeof(double);
     if (lds > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS with the power table (>160 KiB)", lds);
     HIP_TRY(c->d_sh_desc.upload(desc));
-    HIP_TRY(c->d_sh_coef.upload(std::vector<double>(coef, coef + std::max<int64_t>(n_terms, 1))));
-    HIP_TRY(c->d_sh_pow.upload(std::vector<int32_t>(pw, pw + std::max<int64_t>(n_terms, 1))));
+    // (L <= 2: every function is a monomial and there are no terms - upload one zero, read nothing)
+    HIP_TRY(c->d_sh_coef.upload(n_terms > 0 ? std::vector<double>(coef, coef + n_terms) : std::vector<double>(1, 0.0)));
+    HIP_TRY(c->d_sh_pow.upload(n_terms > 0 ? std::vector<int32_t>(pw, pw + n_terms) : std::vector<int32_t>(1, 0)));
     c->enc.sh_desc = c->d_sh_desc.p;
     c->enc.sh_coef = c->d_sh_coef.p;
     c->enc.sh_pow = c->d_sh_pow.p;
     c->enc_lds_bytes = lds;
+    return RANGE_OK;
+}
+
+// keys -> device (float32 rows + the bf16 fragment copy the prefilter of range_topk_stream
+// streams) and the largest row norm, computed on the device.  `keys` may be a host or a device
+// pointer (hipMemcpyDefault).
+static int upload_keys(range_ctx* c, const float* keys, int64_t n_rows, int64_t n_pad) {
+    HIP_TRY(c->d_keys.ensure((size_t)n_pad * KEY_DIM));
+    if (n_pad > n_rows)
+        HIP_TRY(hipMemset(c->d_keys.p + (size_t)n_rows * KEY_DIM, 0, (size_t)(n_pad - n_rows) * KEY_DIM * 4));
+    HIP_TRY(hipMemcpy(c->d_keys.p, keys, (size_t)n_rows * KEY_DIM * 4, hipMemcpyDefault));
+    const int64_t n_tiles = n_pad / BLK;
+    HIP_TRY(c->d_keys_bf16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
+    const int64_t threads = n_tiles * 8 * 64;
+    hipLaunchKernelGGL(keyfrag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, c->d_keys.p,
+                       n_pad, n_tiles, reinterpret_cast<ts_u32x4*>(c->d_keys_bf16.p));
+    HIP_TRY(hipGetLastError());
+    if (!c->ws_topk_sync.p) {
+        HIP_TRY(c->ws_topk_sync.ensure(TOPKS_SYNC_WORDS));
+        HIP_TRY(hipMemset(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4));
+    }
+    uint32_t* scratch = c->ws_topk_sync.p + TOPKS_SYNC_ERROR + 1;
+    HIP_TRY(hipMemset(scratch, 0, 4));
+    hipLaunchKernelGGL(key_norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, 0, c->d_keys.p, n_rows, scratch);
+    HIP_TRY(hipGetLastError());
+    float n2max = 0.f;
+    HIP_TRY(hipMemcpy(&n2max, scratch, 4, hipMemcpyDeviceToHost));   // (synchronises)
+    // (a bound: the float32 sum of squares is within 3e-5 of the exact one)
+    c->key_norm_max = (float)(std::sqrt((double)n2max) * 1.0001);
     return RANGE_OK;
 }
 
@@ -510,39 +556,56 @@ int range_set_bank(range_ctx* c, const float* keys, const float* values, const f
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const int64_t n_pad = (n_rows + BLK - 1) / BLK * BLK;
     c->has_bank = false;
+    c->has_values = false;
     c->kept_B = 0;
-    HIP_TRY(c->d_keys.ensure((size_t)n_pad * KEY_DIM));
     HIP_TRY(c->d_values.ensure((size_t)n_pad * VAL_DIM));
     HIP_TRY(c->d_xyz4.ensure((size_t)n_pad * 4));
-    HIP_TRY(hipMemset(c->d_keys.p, 0, (size_t)n_pad * KEY_DIM * 4));
     HIP_TRY(hipMemset(c->d_values.p, 0, (size_t)n_pad * VAL_DIM * 4));
     HIP_TRY(hipMemset(c->d_xyz4.p, 0, (size_t)n_pad * 16));
-    HIP_TRY(hipMemcpy(c->d_keys.p, keys, (size_t)n_rows * KEY_DIM * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_values.p, values, (size_t)n_rows * VAL_DIM * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy2D(c->d_xyz4.p, 16, xyz, 12, 12, (size_t)n_rows, hipMemcpyHostToDevice));
-    {   // bf16 copy of the keys for the prefilter of range_topk_stream, and the largest row norm
-        const int64_t n_tiles = n_pad / BLK;
-        HIP_TRY(c->d_keys_bf16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
-        const int64_t threads = n_tiles * 8 * 64;
-        hipLaunchKernelGGL(keyfrag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, c->d_keys.p,
-                           n_pad, n_tiles, reinterpret_cast<ts_u32x4*>(c->d_keys_bf16.p));
-        HIP_TRY(hipGetLastError());
+    {
         double n2max = 0.0;
         for (int64_t r = 0; r < n_rows; ++r) {
-            double n2 = 0.0;
-            const float* kr = keys + r * KEY_DIM;
-            for (int e = 0; e < KEY_DIM; ++e) n2 += (double)kr[e] * kr[e];
-            n2max = std::max(n2max, n2);
+            const float* x = xyz + 3 * r;
+            n2max = std::max(n2max, (double)x[0] * x[0] + (double)x[1] * x[1] + (double)x[2] * x[2]);
         }
-        c->key_norm_max = (float)(std::sqrt(n2max) * 1.000001);
+        c->xyz_norm_max = (float)std::sqrt(n2max);
     }
+    int rc = upload_keys(c, keys, n_rows, n_pad);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     c->n_rows = n_rows;
     c->n_pad = n_pad;
     c->row_offset = row_offset;
     c->has_bank = true;
+    c->has_values = true;
     c->vplanes_groups = 0;
     if (c->pv_mode == RANGE_PV_BF16X3) return build_vplanes(c);
+    return RANGE_OK;
+}
+
+int range_set_keys(range_ctx* c, const float* keys, int64_t n_rows, int64_t row_offset) {
+    if (!c || !keys) return fail(RANGE_ERR_INVALID, "null argument");
+    if (n_rows <= 0) return fail(RANGE_ERR_INVALID, "n_rows must be > 0");
+    if (n_rows >= (int64_t)1 << 31) return fail(RANGE_ERR_INVALID, "n_rows too large");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const int64_t n_pad = (n_rows + BLK - 1) / BLK * BLK;
+    c->has_bank = false;
+    c->has_values = false;
+    c->kept_B = 0;
+    c->d_values.release();
+    c->d_xyz4.release();
+    c->d_vplanes.release();
+    c->vplanes_groups = 0;
+    int rc = upload_keys(c, keys, n_rows, n_pad);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    c->n_rows = n_rows;
+    c->n_pad = n_pad;
+    c->row_offset = row_offset;
+    c->has_bank = true;
     return RANGE_OK;
 }
 
@@ -764,9 +827,9 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     return RANGE_OK;
 }
 
-// repeats > 1 (range_topk_stream_timed): the stream kernel is launched `repeats` times back to
-// back between ONE pair of events (identical launches, identical results) and *avg_us receives
-// the time per launch; the merge kernel runs once, afterwards.
+// repeats > 1 (range_topk_stream_timed): the whole call's launches are enqueued `repeats` times
+// back to back between ONE pair of events (identical launches, identical results) and *avg_us
+// receives the time per call.
 static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
                             int64_t* topk_idx, int repeats, float* avg_us, range_stream_t stream) {
     if (!c || !ehat32 || !topk_val || !topk_idx) return fail(RANGE_ERR_INVALID, "null argument");
@@ -778,7 +841,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     const int n_groups = (int)((B + 15) / 16);
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
     // persistent grid: one workgroup per CU (its key tiles fill the LDS), 4 waves each streaming
-    // its own tiles; one candidate list per (group, wave, query).  Query groups sharing one pass
+    // its own tiles; one candidate list of 8 per (query, workgroup).  Query groups sharing one pass
     // over the keys: 2 groups (32 queries) are still at the ridge (16 FLOP per key byte) and take
     // the time of 1.3.
     constexpr int LIST = RANGE_TOPKS_LIST;
@@ -790,12 +853,17 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     int G = c->topks_groups;
     if (G != 1 && G != 2) G = n_groups <= 1 ? 1 : 2;
     const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + NWV - 1) / NWV));
-    const int n_lists = n_wg * NWV;
-    HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * n_lists * 16 * LIST));
-    HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * n_lists * 16));
+    // the merge runs as the tail of the stream kernel while every query finds a workgroup of its own
+    const bool fused = c->topks_fused && B <= n_wg;
+    HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * 16 * n_wg * TOPKS_WL));
+    HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * 16 * n_wg));
     if (!c->ws_exact_count.p) {
-        HIP_TRY(c->ws_exact_count.ensure(1));
-        HIP_TRY(hipMemsetAsync(c->ws_exact_count.p, 0, sizeof(int32_t), s));
+        HIP_TRY(c->ws_exact_count.ensure(2));    // [0] brute-force queries, [1] candidates ranked (diagnostic)
+        HIP_TRY(hipMemsetAsync(c->ws_exact_count.p, 0, 2 * sizeof(int32_t), s));
+    }
+    if (!c->ws_topk_sync.p) {
+        HIP_TRY(c->ws_topk_sync.ensure(TOPKS_SYNC_WORDS));
+        HIP_TRY(hipMemsetAsync(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4, s));
     }
     TopkStreamArgs a{};
     a.keys = c->d_keys.p;
@@ -807,10 +875,21 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     a.n_blocks = n_blocks;
     a.n_groups = n_groups;
     a.keys_bf16 = c->d_keys_bf16.p;
+    a.sync = c->ws_topk_sync.p;
+    a.fused = fused ? 1 : 0;
+    a.k = k;
+    a.row_offset = c->row_offset;
+    a.force_exact = c->topks_force_exact ? 1 : 0;
+    a.exact_count = c->ws_exact_count.p;
+    a.eps_rel = bf16 ? TSB_EPS_REL : 0.f;
+    a.kmax = c->key_norm_max;
+    a.oval = topk_val;
+    a.oidx = topk_idx;
 #ifdef RANGE_EXP_TS_STAMPS
     static DevBuf<unsigned long long> stamps_buf;
-    HIP_TRY(stamps_buf.ensure((size_t)n_lists * 8));
-    HIP_TRY(hipMemsetAsync(stamps_buf.p, 0, (size_t)n_lists * 64, s));
+    const int n_lists = n_wg * NWV;
+    HIP_TRY(stamps_buf.ensure((size_t)n_lists * 8 + (size_t)n_wg * 16));
+    HIP_TRY(hipMemsetAsync(stamps_buf.p, 0, ((size_t)n_lists * 8 + (size_t)n_wg * 16) * 8, s));
     a.stamps = stamps_buf.p;
 #endif
     int rc = RANGE_OK;
@@ -822,12 +901,6 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         hipLaunchKernelGGL((topk_stream_kernel<GG, LIST, NWV, DEP>), dim3((unsigned)n_wg),          \
                            dim3(NWV * 64), TOPKS_LDS_BYTES, s, a);                                  \
     } while (0)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (repeats > 1) {
-        ev0 = c->get_event();
-        ev1 = c->get_event();
-        HIP_TRY(hipEventRecord(ev0, s));
-    }
 #define RANGE_TOPKS_LAUNCH_BF16(GG)                                                                 \
     do {                                                                                            \
         rc = set_dyn_lds(topk_stream_bf16_kernel<GG, LIST>, TOPKS_LDS_BYTES);                       \
@@ -836,6 +909,12 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         hipLaunchKernelGGL((topk_stream_bf16_kernel<GG, LIST>), dim3((unsigned)n_wg), dim3(256),    \
                            TOPKS_LDS_BYTES, s, a);                                                  \
     } while (0)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (repeats > 1) {
+        ev0 = c->get_event();
+        ev1 = c->get_event();
+        HIP_TRY(hipEventRecord(ev0, s));
+    }
     for (int rep = 0; rep < std::max(1, repeats); ++rep) {
         if (bf16) {
             if (G == 1) RANGE_TOPKS_LAUNCH_BF16(1);
@@ -844,10 +923,17 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
             if (G == 1) RANGE_TOPKS_LAUNCH(1);
             else RANGE_TOPKS_LAUNCH(2);
         }
+        HIP_TRY(hipGetLastError());
+        if (!fused) {
+            rc = set_dyn_lds(topk_merge_kernel<TOPKS_WL>, TOPKM_LDS_BYTES);
+            if (rc) return rc;
+            ProfScope ps(c, RANGE_PROF_TOPK_MERGE, s);
+            hipLaunchKernelGGL(topk_merge_kernel<TOPKS_WL>, dim3((unsigned)B), dim3(256), TOPKM_LDS_BYTES, s, a, n_wg);
+            HIP_TRY(hipGetLastError());
+        }
     }
 #undef RANGE_TOPKS_LAUNCH
 #undef RANGE_TOPKS_LAUNCH_BF16
-    HIP_TRY(hipGetLastError());
     if (repeats > 1) {
         HIP_TRY(hipEventRecord(ev1, s));
         HIP_TRY(hipEventSynchronize(ev1));
@@ -859,7 +945,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     }
 #ifdef RANGE_EXP_TS_STAMPS
     if (std::getenv("RANGE_TOPKS_STAMPS")) {   // per stamp: earliest / median / latest wave, us after the first wave's start
-        std::vector<unsigned long long> h((size_t)n_lists * 8);
+        std::vector<unsigned long long> h((size_t)n_lists * 8 + (size_t)n_wg * 16);
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpy(h.data(), stamps_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
@@ -897,6 +983,20 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
             std::sort(v.begin(), v.end());
             std::fprintf(stderr, " %.1f/%.1f/%.1f", v.front(), v[v.size() / 2], v.back());
         }
+        std::fprintf(stderr, "\n  tail stamps (us after the first wave's start: min med max over the workgroups that have it)");
+        for (int i = 0; i < 16; ++i) {
+            std::vector<double> v;
+            for (int w = 0; w < n_wg; ++w) {
+                const unsigned long long t = h[(size_t)n_lists * 8 + (size_t)w * 16 + i];
+                if (t && i == 14) {   // shader clocks of the merge / its real time -> MHz
+                    const unsigned long long b0 = h[(size_t)n_lists * 8 + (size_t)w * 16 + 3], b1 = h[(size_t)n_lists * 8 + (size_t)w * 16 + 15];
+                    if (b1 > b0) v.push_back((double)t / ((double)(b1 - b0) * 0.01));
+                } else if (t) v.push_back((double)(t - t0) * 0.01);
+            }
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            std::fprintf(stderr, " | %d (%zu): %.1f %.1f %.1f", i, v.size(), v.front(), v[v.size() / 2], v.back());
+        }
         std::fprintf(stderr, "\n  by wave in workgroup:");
         for (int x = 0; x < 4; ++x) {
             std::vector<double> v;
@@ -907,14 +1007,6 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         std::fprintf(stderr, "\n");
     }
 #endif
-    {
-        ProfScope ps(c, RANGE_PROF_TOPK_MERGE, s);
-        hipLaunchKernelGGL(topk_merge_kernel<LIST>, dim3((unsigned)B), dim3((unsigned)((n_lists + 63) / 64 * 64)),
-                           0, s, c->ws_cand_keys.p, c->ws_cand_dmax.p, n_lists, B, (int)k, c->row_offset,
-                           c->d_keys.p, ehat32, c->n_rows, c->topks_force_exact ? 1 : 0,
-                           c->ws_exact_count.p, bf16 ? TSB_EPS_REL : 0.f, c->key_norm_max, topk_val, topk_idx);
-    }
-    HIP_TRY(hipGetLastError());
     return RANGE_OK;
 }
 
@@ -934,10 +1026,22 @@ int range_topk_stream_exact_count(range_ctx* c, int64_t* count) {
     *count = 0;
     if (!c->ws_exact_count.p) return RANGE_OK;
     DeviceGuard g(c->device);
-    int32_t v = 0;
+    int32_t v[2] = {0, 0};
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&v, c->ws_exact_count.p, sizeof v, hipMemcpyDeviceToHost));
-    *count = v;
+    HIP_TRY(hipMemcpy(v, c->ws_exact_count.p, sizeof v, hipMemcpyDeviceToHost));
+    *count = v[0];
+    if (std::getenv("RANGE_TOPKS_DIAG")) std::fprintf(stderr, "range_topk_stream: %d candidates ranked so far\n", v[1]);
+    if (c->ws_topk_sync.p) {
+        uint32_t sy = 0;
+        HIP_TRY(hipMemcpy(&sy, c->ws_topk_sync.p + TOPKS_SYNC_ERROR, sizeof sy, hipMemcpyDeviceToHost));
+        if (sy != 0) {
+            // a merging workgroup of range_topk_stream gave up waiting for the others (the grid was
+            // not resident as a whole): its query's results were marked invalid (index -1, NaN)
+            HIP_TRY(hipMemset(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4));
+            return fail(RANGE_ERR_HIP, "range_topk_stream: a merging workgroup timed out waiting for the "
+                        "stream workgroups (results of that call carry index -1 / NaN)");
+        }
+    }
     return RANGE_OK;
 }
 

@@ -190,3 +190,84 @@ def test_topk_stream_bf16_prefilter_is_exact(monkeypatch):
     assert torch.equal(ai, bi) and torch.equal(av, bv)
     assert ai.cpu().numpy().tolist() == [list(range(16))] * 3     # ties: lower rows first
     assert pre3.topk_stream_exact_count() == 3
+
+
+@pytest.mark.parametrize("level", ["lanes", "waves"])
+def test_topk_stream_drop_seen_by_every_merge_level(level):
+    """The candidate lists are merged lane -> wave -> workgroup, each merge over shuffles between the
+    4 lanes (j, g) of a query, and what a merge drops must reach the exactness check whichever of
+    the 4 lanes saw it go.  'lanes': five of a query's best rows sit in lane groups 2 and 3 of ONE
+    wave's tile (3 + 2: no lane list overflows, the pair merge of lanes (2,3) does when lists are 4
+    deep).  'waves': ten of its best rows sit in waves 2 and 3 of ONE workgroup (5 + 5, one per
+    lane list: the pair merge of waves (2,3) drops two of them).  Either way the result must be the
+    oracle's - through the lists if they held everything, through the brute-force path otherwise."""
+    rng = np.random.default_rng(5)
+    N, d, k = 20000, 256, 16
+    keys = rng.standard_normal((N, d)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+
+    def plant(row, b, s):
+        u = rng.standard_normal(d)
+        u -= u.dot(q[b].astype(np.float64)) * q[b]
+        u /= np.linalg.norm(u)
+        keys[row] = (s * q[b] + np.sqrt(1 - s * s) * u).astype(np.float32)
+
+    # rows of a 16-row tile held by lane group g (attend_kernels.h: pi_row): g=0 {0,1,8,9}, g=1 {2,3,10,11},
+    # g=2 {4,5,12,13}, g=3 {6,7,14,15}; wave w of workgroup 0 streams tile w * 256 first (256 workgroups)
+    if level == "lanes":
+        spots = [(0, 16 * 7 + r) for r in (4, 5, 12, 6, 7)]                      # tile 7: lanes g=2 (3 rows), g=3 (2)
+    else:
+        spots = [(0, 16 * (256 * w) + r) for w in (2, 3) for r in (0, 2, 4, 6, 8)]   # waves 2, 3 of workgroup 0
+    for i, (b, row) in enumerate(spots):
+        plant(row, b, 0.9 + 1e-3 * i)
+    for mode in ("bf16", "f32"):
+        if mode == "f32":
+            os.environ["RANGE_TOPKS_KEYS"] = "f32"
+        try:
+            eng = _native.HipEngine("cuda:0")
+        finally:
+            os.environ.pop("RANGE_TOPKS_KEYS", None)
+        eng.set_keys(keys)
+        tv, ti = eng.topk_stream(torch.from_numpy(q).cuda(), k)
+        s64 = q.astype(np.float64) @ keys.astype(np.float64).T
+        rv, ri = O.topk64(s64, k)
+        assert np.array_equal(ti.cpu().numpy(), ri), mode
+        np.testing.assert_allclose(tv.cpu().numpy(), rv, rtol=0, atol=1e-6)     # f32 dot of 256 terms near 0.9
+
+
+def test_keys_only_bank_serves_topk_and_nothing_else():
+    """range_set_keys: the keys column alone (host array or device tensor) answers topk_stream like
+    the full bank does; calls that need the values fail with RANGE_ERR_STATE."""
+    rng = np.random.default_rng(9)
+    N = 5003
+    keys = rng.standard_normal((N, 256)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    q = torch.from_numpy(keys[rng.integers(0, N, 40)] + 0.1 * rng.standard_normal((40, 256)).astype(np.float32)).cuda()
+    full = _native.HipEngine("cuda:0")
+    full.set_bank(keys, np.zeros((N, 1024), np.float32), np.zeros((N, 3), np.float32), 77)
+    fv, fi = full.topk_stream(q, 16)
+    for src in (keys, torch.from_numpy(keys).cuda()):
+        eng = _native.HipEngine("cuda:0")
+        eng.set_keys(src, 77)
+        tv, ti = eng.topk_stream(q, 16)
+        assert torch.equal(ti, fi) and torch.equal(tv, fv)
+        with pytest.raises(_native.RangeNativeError, match="keys-only"):
+            eng.scan_stats(q, torch.zeros((40, 4), device="cuda"), 12.0, 0.0)
+
+
+def test_unnormalised_bank_is_refused_by_the_softmax():
+    """The constant-shift softmax statistics need unit keys (range/range.py:85-89 normalises them);
+    a bank that skipped it is refused by scan_stats / attend instead of overflowing (advice r2)."""
+    rng = np.random.default_rng(2)
+    N = 300
+    keys = rng.standard_normal((N, 256)).astype(np.float32)          # norms ~16
+    eng = _native.HipEngine("cuda:0")
+    eng.set_bank(keys, np.zeros((N, 1024), np.float32), np.zeros((N, 3), np.float32))
+    q = torch.nn.functional.normalize(torch.randn(8, 256), dim=1).cuda()
+    with pytest.raises(_native.RangeNativeError, match="not L2-normalised"):
+        eng.scan_stats(q, torch.zeros((8, 4), device="cuda"), 12.0, 0.0)
+    tv, ti = eng.topk_stream(q, 4)                                     # the top-k takes any norm
+    s64 = q.cpu().numpy().astype(np.float64) @ keys.astype(np.float64).T
+    assert np.array_equal(ti.cpu().numpy(), O.topk64(s64, 4)[1])

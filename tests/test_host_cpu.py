@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.range_abi_version() == 4
+    assert lib.range_abi_version() == 5
     assert lib.range_last_error() is not None
     # the ridge-probe header, same library
     from range_amd import _probe_native
@@ -138,6 +138,38 @@ def test_no_foreign_m0_writes(tmp_path):
     spec.loader.exec_module(mod)
     bad = mod.check(str(out), ["attend_kernel", "scan_stats_kernel", "attend_bf16x3_kernel"])
     assert not bad, bad[:5]
+    # third check: the stream top-k kernels load their first query operand by inline asm into
+    # accumulator registers and wait for it by hand (topk_stream.h: TopkQLoad / topk_qwait) - hipcc
+    # must not read, copy or overwrite those registers between a load and the wait that covers it,
+    # the kernels must not use scratch memory, and everything workgroups hand each other goes through
+    # global (not flat) agent-scope accesses
+    n_stream = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if "topk_stream" not in name:
+            continue
+        n_stream += 1
+        body = k.splitlines()
+        loads = [i for i, l in enumerate(body)
+                 if re.search(r"global_load_dwordx4 a\[\d+:\d+\], v\[\d+:\d+\], off offset:(0x[0-9a-f]+|\d+)\s*$", l)]
+        waits = [i for i, l in enumerate(body) if re.search(r"s_waitcnt vmcnt\((32|48)\)", l)]
+        assert len(loads) in (16, 32) and len(waits) == len(loads) // 16, (name, len(loads), waits)
+        for grp, w in enumerate(waits):
+            regs = set()
+            for i in loads[16 * grp:16 * grp + 16]:
+                lo, hi = map(int, re.search(r"a\[(\d+):(\d+)\]", body[i]).groups())
+                regs.update(range(lo, hi + 1))
+            for line in body[loads[16 * grp]:w]:
+                if "global_load_dwordx4 a[" in line:
+                    continue
+                code = line.split(";")[0]
+                used = {int(x) for x in re.findall(r"\ba(\d+)\b", code)}
+                for lo, hi in re.findall(r"a\[(\d+):(\d+)\]", code):
+                    used.update(range(int(lo), int(hi) + 1))
+                assert not (used & regs), f"{name}: query register touched before its wait: {line.strip()}"
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", k), f"{name} uses scratch memory"
+        assert not re.search(r"\n\s*flat_(load|store|atomic)", k), f"{name}: flat memory access"
+    assert n_stream == 4
 
 
 def test_bankfile_roundtrip_and_shards(tmp_path):
