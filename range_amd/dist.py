@@ -63,18 +63,24 @@ class ShardedRange:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_chunks = n_chunks   # None: 4 chunks when there is a peer to exchange with
-        # gathered / chunk-major / receive buffers, allocated once per (name, shape): a step then
-        # makes no allocation of its own besides the engine's outputs (torch's caching allocator)
+        # gathered / chunk-major / receive buffers: one per name, sized to the largest request seen
+        # (a step then makes no allocation of its own besides the engine's outputs)
         self._bufs = {}
         self._timing = False
         self._events = []
 
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
-        key = (name, tuple(shape), dtype, str(device))
+        """One flat buffer per (name, dtype, device), grown to the largest request seen; a request is
+        a view of its head.  (A buffer per distinct shape would grow without bound under varying
+        batch sizes: ragged last batches, a serving loop.)"""
+        key = (name, dtype, str(device))
+        n = 1
+        for d in shape:
+            n *= int(d)
         t = self._bufs.get(key)
-        if t is None:
-            t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
-        return t
+        if t is None or t.numel() < n:
+            t = self._bufs[key] = torch.empty(max(n, 1), dtype=dtype, device=device)
+        return t[:n].view(tuple(shape))
 
     # -- exposed communication time ------------------------------------------------------------
     def comm_timing(self, on: bool):
@@ -202,7 +208,7 @@ class ShardedRange:
         kept = self.engine.kept_queries() == W * B
         stats = self._reduce_stats(stats_local)
         pending = []
-        for lo, hi in chunks:
+        for ci, (lo, hi) in enumerate(chunks):
             first, n = W * lo, W * (hi - lo)
             if kept:
                 part = self.engine.attend_kept(first, xq_all[first:first + n], self.tau_sem,
@@ -211,7 +217,7 @@ class ShardedRange:
                 part = self.engine.attend(e32_all[first:first + n], xq_all[first:first + n],
                                           self.tau_sem, self.tau_geo, self.beta,
                                           stats[first:first + n])
-            work, get, keep = self._all_to_all(part, f"fwd{lo}")
+            work, get, keep = self._all_to_all(part, f"fwd{ci}")
             pending.append((work, get, keep, lo, hi))
         outs = []
         for work, get, keep, lo, hi in pending:
@@ -222,6 +228,83 @@ class ShardedRange:
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     __call__ = forward
+
+    #: scanned queries (all ranks') per outer step of ``embed`` / ``embed_sweep``: bounds the
+    #: per-rank workspace like LocationEncoder.chunk_size does on one GPU (kept logits: 4 B x
+    #: scanned queries x local rows; split slabs: splits x scanned queries x 4 KB)
+    scan_chunk = 16384
+
+    def _max_over_ranks(self, n: int, device) -> int:
+        t = torch.tensor([n], dtype=torch.int64,
+                         device=device if dist.get_backend(self.group) != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _steps(self, lonlat: torch.Tensor, chunk: Optional[int]):
+        """Outer steps of a ragged job: every rank brings its OWN number of queries (0 allowed); the
+        ranks agree on the largest count (one scalar all-reduce), walk it in steps of ``chunk``
+        queries per rank and pad their share of a step to the step's size with copies of a dummy
+        location - every collective of a step then has the same shape on every rank.  Yields
+        (lo, n_own, padded (c,2) tensor)."""
+        if lonlat.dim() != 2 or lonlat.shape[1] != 2:
+            raise ValueError(f"lonlat must be (B,2) (lon,lat) degrees, got {tuple(lonlat.shape)}")
+        B = lonlat.shape[0]
+        b_max = self._max_over_ranks(B, lonlat.device)
+        if chunk is None:
+            chunk = max(64, self.scan_chunk // self.world // 64 * 64)
+        chunk = max(1, int(chunk))
+        for lo in range(0, b_max, chunk):
+            c = min(chunk, b_max - lo)
+            own = lonlat[lo:lo + c]
+            n_own = own.shape[0]
+            if n_own < c:
+                pad = self._buf("pad:q", (c, 2), lonlat.dtype, lonlat.device)
+                pad.zero_()
+                pad[:n_own] = own
+                own = pad
+            yield lo, n_own, own.contiguous()
+
+    @torch.no_grad()
+    def embed(self, lonlat: torch.Tensor, chunk: Optional[int] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The product entry of the row-sharded path: this rank's (B,2) queries -> its (B,1280)
+        float64 embeddings (device tensor), for ANY per-rank B (ragged across ranks, zero on some),
+        in outer steps of ``chunk`` queries per rank (default: ``scan_chunk`` scanned queries per
+        step).  Collective: every rank of the group must call it."""
+        B = lonlat.shape[0]
+        if out is None:
+            out = torch.empty((B, 1280), dtype=torch.float64, device=lonlat.device)
+        for lo, n_own, q in self._steps(lonlat, chunk):
+            res = self.forward(q)
+            if n_own:
+                out[lo:lo + n_own] = res[:n_own]
+        return out
+
+    @torch.no_grad()
+    def embed_sweep(self, lonlat: torch.Tensor, betas, chunk: Optional[int] = None) -> torch.Tensor:
+        """``embed`` for several beta values at once (one pass 1 and two passes 2 per step whatever
+        the number of betas): (len(betas), B, 1280) float64 on the device."""
+        betas = [float(b) for b in betas]
+        B = lonlat.shape[0]
+        out = torch.empty((len(betas), B, 1280), dtype=torch.float64, device=lonlat.device)
+        for lo, n_own, q in self._steps(lonlat, chunk):
+            res = self.sweep(q, betas)
+            if n_own:
+                out[:, lo:lo + n_own] = res[:, :n_own]
+        return out
+
+    @torch.no_grad()
+    def embed_topk(self, lonlat: torch.Tensor, k: int = 16, chunk: Optional[int] = None):
+        """``topk`` for ragged per-rank batches: (values (B,k) f32, global indices (B,k) i64)."""
+        B = lonlat.shape[0]
+        tv = torch.empty((B, k), dtype=torch.float32, device=lonlat.device)
+        ti = torch.empty((B, k), dtype=torch.int64, device=lonlat.device)
+        for lo, n_own, q in self._steps(lonlat, chunk):
+            v, i = self.topk(q, k)
+            if n_own:
+                tv[lo:lo + n_own] = v[:n_own]
+                ti[lo:lo + n_own] = i[:n_own]
+        return tv, ti
 
     @torch.no_grad()
     def sweep(self, lonlat: torch.Tensor, betas) -> torch.Tensor:
@@ -243,7 +326,7 @@ class ShardedRange:
         kept = self.engine.kept_queries() == W * B
         stats = self._reduce_stats(stats_local)
         pending = []
-        for lo, hi in chunks:
+        for ci, (lo, hi) in enumerate(chunks):
             first, n = W * lo, W * (hi - lo)
             sl = slice(first, first + n)
             parts = []
@@ -254,7 +337,7 @@ class ShardedRange:
                 else:
                     parts.append(self.engine.attend(e32_all[sl], xq_all[sl], self.tau_sem,
                                                     self.tau_geo, b, stats[sl]))
-            ex = [self._all_to_all(p, f"sweep{lo}:{j}") for j, p in enumerate(parts)]
+            ex = [self._all_to_all(p, f"sweep{ci}:{j}") for j, p in enumerate(parts)]
             pending.append((ex, lo, hi))
         out = torch.empty((len(betas), B, e64.shape[1] + 1024), dtype=torch.float64,
                           device=e64.device)

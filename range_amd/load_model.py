@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from argparse import Namespace
 
-from .range import LocationEncoder
+from .range import LocationEncoder, ShardedLocationEncoder
 
 
 def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwargs):
@@ -24,7 +24,12 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
             coefficients from (default: regenerated, range_amd/sh_table.py); ``pv_mode`` -
             'exact' (default: float32 products like the reference, range.py:217/:236) or the
             opt-in 'bf16x3' (retrieval products on the bf16 matrix cores, both operands split in
-            three planes: ~1.5x the throughput, agreement with the exact products to ~1e-7).
+            three planes: ~1.5x the throughput, agreement with the exact products to ~1e-7);
+            ``shards`` - W (or True): the bank ROW-SHARDED over the W ranks of the initialised
+            ``torch.distributed`` job (one process per GPU, RCCL); every rank calls ``load_model``
+            with the same arguments and ``device`` = its own GPU and gets a model with the same
+            call contract (``range_amd.range.ShardedLocationEncoder``); ``group`` - the process
+            group to shard over (default: the world).
     """
     if pretrained_path is None:
         raise ValueError("Please provide the pretrained model path.")      # load_model.py:31-32
@@ -37,9 +42,14 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
         beta = None
     args = Namespace(location_model_name=model_name, pretrained_path=pretrained_path,
                      device=device, range_db=db_path, beta=beta)           # :45-46
-    for opt in ("sh_eval", "sh_source", "pv_mode"):
+    for opt in ("sh_eval", "sh_source", "pv_mode", "shards"):
         if opt in kwargs:
             setattr(args, opt, kwargs[opt])
-    model = LocationEncoder(args)
+    if kwargs.get("shards"):
+        if "RANGE" not in model_name:
+            raise ValueError("shards= applies to the RANGE / RANGE+ models (the bank is what is sharded)")
+        model = ShardedLocationEncoder(args, group=kwargs.get("group"))
+    else:
+        model = LocationEncoder(args)
     model.eval()
     return model

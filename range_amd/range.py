@@ -251,3 +251,131 @@ class LocationEncoder(nn.Module):
             return (torch.empty((0, k), dtype=torch.float32, device=x.device),
                     torch.empty((0, k), dtype=torch.int64, device=x.device))
         return torch.cat(vals), torch.cat(idxs)
+
+
+class ShardedLocationEncoder(nn.Module):
+    """RANGE / RANGE+ over a bank ROW-SHARDED across the ranks of a ``torch.distributed`` group (one
+    process per GPU, backend "nccl" = RCCL over xGMI): ``load_model(..., shards=W)`` in every rank of
+    a W-process job.  The reference has no distributed code; the call surface is its
+    ``LocationEncoder``'s (range/range.py:69, :206-240), so the same script runs under
+    ``torchrun --nproc-per-node W`` unchanged:
+
+      ``model(coords)``              every rank passes the SAME (B,2) batch and gets the FULL
+                                     (B,1280) float64 ``numpy.ndarray`` back (rank r embeds rows
+                                     [r B/W, (r+1) B/W) against all shards, one all-gather of the
+                                     results follows) - any B, also B < W;
+      ``model(coords, local=True)``  data-parallel callers: ``coords`` are THIS rank's own queries
+                                     (any count per rank, zero allowed), the result is their rows.
+
+    Each rank loads and uploads only its rows of the bank (a ``.rbank`` file is memory-mapped, so a
+    rank reads just its slice; an ``.npz`` is read whole by every rank and sliced)."""
+
+    is_sharded = True
+
+    def __init__(self, args, group=None):
+        super().__init__()
+        import torch.distributed as dist
+        from .dist import ShardedRange, shard_rows
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("load_model(..., shards=W) needs an initialised torch.distributed job "
+                               "(torchrun --nproc-per-node W; range_amd.dist.init_from_env())")
+        self.args = args
+        self.location_model_name = args.location_model_name
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        want = getattr(args, "shards", None)
+        if isinstance(want, int) and not isinstance(want, bool) and want != self.world:
+            raise ValueError(f"shards={want} but the process group has {self.world} ranks")
+        if self.location_model_name == "RANGE":                          # range.py:102-105
+            self.args.temp = TEMP_RANGE
+            print(f"Using RANGE with temperature {self.args.temp}")
+        elif self.location_model_name == "RANGE+":                       # :107-112
+            self.args.geo_temp = TEMP_GEO
+            self.args.temp = TEMP_RANGE_PLUS
+            print(f"Using RANGE+ with temperatures {self.args.temp} and {self.args.geo_temp}")
+        else:
+            raise ValueError("Unimplemented RANGE model")                 # :113-114
+        bank = load_bank(args.range_db)
+        enc = read_checkpoint(args.pretrained_path)
+        if enc.embed_dim != 256:
+            raise ValueError(f"checkpoint embed_dim {enc.embed_dim} != bank key width 256")
+        self.location_feature_dim = 1024 + 256                           # :86
+        self.encoder_params = enc
+        self.n_bank_rows = bank.n_rows
+        if self.n_bank_rows < self.world:
+            raise ValueError(f"bank of {self.n_bank_rows} rows cannot be sharded over {self.world} ranks")
+        self.row_range = shard_rows(bank.n_rows, self.world, self.rank)
+        self._device = _device_of(args.device)
+        self.engine = make_engine(enc, bank.rows(*self.row_range), self._device, row_offset=self.row_range[0],
+                                  sh_eval=getattr(args, "sh_eval", None), sh_source=getattr(args, "sh_source", None),
+                                  pv_mode=getattr(args, "pv_mode", None))
+        self.sharded = ShardedRange(self.engine, self.location_model_name, args.beta, group=group)
+        self.eval()
+
+    def _coords(self, coords) -> torch.Tensor:
+        if not torch.is_tensor(coords):
+            coords = torch.as_tensor(np.asarray(coords))
+        if coords.dim() != 2 or coords.shape[1] != 2:
+            raise ValueError(f"coords must be (B,2) (lon,lat) degrees, got {tuple(coords.shape)}")
+        return coords.to(device=self.engine.device, dtype=torch.float64).contiguous()
+
+    def _own_rows(self, B: int):
+        return (B * self.rank) // self.world, (B * (self.rank + 1)) // self.world
+
+    def _gather_rows(self, own: torch.Tensor, B: int) -> torch.Tensor:
+        """Every rank's rows of a full-batch result -> the full result on every rank (one padded
+        all-gather: the row counts differ by at most one)."""
+        import torch.distributed as dist
+        W = self.world
+        per = (B + W - 1) // W
+        send = torch.zeros((per,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+        send[:own.shape[0]] = own
+        staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+        src = send.cpu() if staged else send
+        allr = torch.empty((W * per,) + tuple(own.shape[1:]), dtype=own.dtype, device=src.device)
+        dist.all_gather_into_tensor(allr, src, group=self.group)
+        parts = []
+        for r in range(W):
+            n = (B * (r + 1)) // W - (B * r) // W
+            parts.append(allr[r * per:r * per + n])
+        return torch.cat(parts, dim=0)
+
+    @torch.no_grad()
+    def forward(self, coords, return_device: bool = False, local: bool = False):
+        x = self._coords(coords)
+        if local:
+            out = self.sharded.embed(x)
+            return out if return_device else out.cpu().numpy()
+        B = x.shape[0]
+        lo, hi = self._own_rows(B)
+        full = self._gather_rows(self.sharded.embed(x[lo:hi]), B)
+        if return_device:
+            return full.to(self.engine.device)
+        return full.cpu().numpy()                                        # range.py:240: a host ndarray
+
+    @torch.no_grad()
+    def sweep(self, coords, betas, return_device: bool = False, local: bool = False):
+        """(len(betas), B, 1280) float64 for several beta values (BASELINE config "beta sweep")."""
+        if self.location_model_name != "RANGE+":
+            raise ValueError("sweep() is defined for RANGE+ only")
+        x = self._coords(coords)
+        if local:
+            out = self.sharded.embed_sweep(x, betas)
+            return out if return_device else out.cpu().numpy()
+        B = x.shape[0]
+        lo, hi = self._own_rows(B)
+        own = self.sharded.embed_sweep(x[lo:hi], betas)                  # (nb, b_own, 1280)
+        full = self._gather_rows(own.permute(1, 0, 2).contiguous(), B).permute(1, 0, 2).contiguous()
+        return full.to(self.engine.device) if return_device else full.cpu().numpy()
+
+    @torch.no_grad()
+    def topk(self, coords, k: int = 16, local: bool = False):
+        """Global top-k over all shards: (values (B,k) float32, global bank rows (B,k) int64)."""
+        x = self._coords(coords)
+        if local:
+            return self.sharded.embed_topk(x, k)
+        B = x.shape[0]
+        lo, hi = self._own_rows(B)
+        tv, ti = self.sharded.embed_topk(x[lo:hi], k)
+        return (self._gather_rows(tv, B).to(self.engine.device), self._gather_rows(ti, B).to(self.engine.device))

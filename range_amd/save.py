@@ -114,10 +114,30 @@ def save_embeddings(args, train_loader, val_loader, location_model):
     embeddings_dir = os.path.join(args.embeddings_dir, args.location_model_name)
     if not os.path.exists(embeddings_dir):
         print(f"Creating new directory {embeddings_dir}")
-        os.makedirs(embeddings_dir)
+        os.makedirs(embeddings_dir, exist_ok=True)       # (several ranks of a sharded job may get here together)
     train_path = os.path.join(embeddings_dir, f"{args.task_name}_train.npz")
     val_path = os.path.join(embeddings_dir, f"{args.task_name}_val.npz")
     location_model.eval()
+    if getattr(location_model, "is_sharded", False):
+        # row-sharded model (load_model(..., shards=W)): every rank of the job runs this function over
+        # the SAME loaders; model(coords) is collective and returns the full batch on every rank
+        # (range.ShardedLocationEncoder), rank 0 writes the files
+        import torch.distributed as dist
+        for loader, path in ((train_loader, train_path), (val_loader, val_path)):
+            coords_list, y_list, embeddings_list = [], [], []
+            for coords, y in loader:                                     # range/utils/save.py:24-37
+                coords_list.append(coords.cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords))
+                y_list.append(y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y))
+                embeddings_list.append(location_model(coords))
+            if dist.get_rank(location_model.group) == 0:
+                np.savez(path, coords=np.concatenate(coords_list, axis=0),
+                         embeddings=np.concatenate(embeddings_list, axis=0),
+                         y=np.concatenate(y_list, axis=0))
+                print(f"File saved to {path}")
+        dist.barrier(location_model.group)
+        if dist.get_rank(location_model.group) == 0:
+            print(f"File saved to {train_path} and {val_path}")
+        return
     pipe = EmbeddingPipeline(location_model)
     for loader, path in ((train_loader, train_path), (val_loader, val_path)):
         coords_list, y_list = [], []

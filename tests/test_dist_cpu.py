@@ -163,3 +163,53 @@ def test_shard_rows_cover():
             spans = [shard_rows(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def _ragged_worker(rank, world, port, ret):
+    """embed / embed_sweep / embed_topk: every rank brings its OWN number of queries (one of them
+    none at all), walked in outer steps shorter than the largest count."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, L, H = 601, 10, 64
+        locs, vals, keys = synth.make_bank(N, 11)
+        full = O.prep_bank(locs, vals, keys)
+        r0, r1 = shard_rows(N, world, rank)
+        shard = O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1])
+        w = synth.make_encoder_weights(L, H, 256, 2, 5)
+        model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5)
+        for counts, chunk in (((5, 0, 130), 64), ((1, 1, 0), None), ((0, 70, 0), 64), ((64, 64, 64), 32)):
+            B = counts[rank]
+            q = synth.make_queries(max(B, 1), seed=300 + rank)[:B]
+            out = model.embed(torch.from_numpy(q), chunk=chunk).numpy()
+            assert out.shape == (B, 1280)
+            if B:
+                err = float(np.abs(out - O.forward(q, w, L, full, "RANGE+", 0.5)).max())
+                assert err < 1e-5, (counts, err)
+            sw = model.embed_sweep(torch.from_numpy(q), (0.0, 1.0), chunk=chunk).numpy()
+            assert sw.shape == (2, B, 1280)
+            tv, ti = model.embed_topk(torch.from_numpy(q), 8, chunk=chunk)
+            assert tuple(tv.shape) == (B, 8) and tuple(ti.shape) == (B, 8)
+            if B:
+                for j, b in enumerate((0.0, 1.0)):
+                    assert float(np.abs(sw[j] - O.forward(q, w, L, full, "RANGE+", b)).max()) < 1e-5
+                s, _ = O.logits64(O.encode(q, w, L), q, full)
+                assert np.array_equal(ti.numpy(), O.topk64(s, 8)[1])
+        # the communication buffers are one per name, not one per batch shape
+        n_buf = len(model._bufs)
+        for B in (3, 17, 40, 9):
+            model.embed(torch.from_numpy(synth.make_queries(B, seed=B)))
+        assert len(model._bufs) == n_buf
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_embed_ragged_batches_gloo():
+    world = 3
+    ret = mp.Manager().dict()
+    mp.spawn(_ragged_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)

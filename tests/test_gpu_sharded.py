@@ -1,0 +1,149 @@
+"""The row-sharded PRODUCT entry at BASELINE's multi-GPU shapes, on what a one-GPU box offers: two
+rank processes with the real engine sharing cuda:0, each holding half of range_db_large, collectives
+over gloo (staged through the host, range_amd/dist.py) - ``load_model(..., shards=2)``:
+
+  C4 shape  RANGE+ beta=0.5, range_db_large row-sharded, 100 000 queries (50 000 per rank, ragged
+            by one, in outer steps of 8 192 per rank): every row through the planted-column
+            properties, a 256-query sample per rank against the float64 oracle over the WHOLE bank;
+  C5 shape  the beta sweep {0, .25, .5, .75, 1} over the full bank, 20 000 queries: every beta's sample
+            against the oracle, the beta = 0.5 slice against the plain forward;
+  drop-in   ``model(coords)`` with the same batch on every rank returns the full batch (B = 1 001, 1);
+            ``save_embeddings`` driven by the sharded model writes the reference's files from rank 0.
+
+What only a real multi-GPU node can add is RCCL itself and the timing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+L, H, SEED, N = 40, 512, 1234, 100_000
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bank_arrays():
+    from range_amd import synth
+    locs, vals, keys = synth.make_bank(N, 2024)
+    vals = vals.copy()
+    vals[:, 0] = 1.0            # constant columns: reproduced iff the weights of a row sum to one over ALL shards
+    vals[:, 1] = -2.5
+    return locs, vals, keys
+
+
+def _sample_check(out_rows, q_rows, obank, w, betas):
+    """out_rows: (nb, n, 1280) device results of the sampled queries for each beta."""
+    from oracle import range_oracle as O
+    for j, b in enumerate(betas):
+        got = out_rows[j]
+        e = got[:, 1024:]
+        low = np.abs(q_rows[:, 1]) <= 30
+        np.testing.assert_allclose(e[low], O.encode(q_rows[low], w, L), rtol=0, atol=5e-9)
+        np.testing.assert_allclose(got[:, :1024], O.retrieve64(e, q_rows, obank, "RANGE+", b), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(got, O.retrieve(e, q_rows, obank, "RANGE+", b), rtol=0, atol=1e-4)
+
+
+def _rank(rank, world, port, ck, rbank, tmp, ret):
+    import torch.distributed as dist
+    from oracle import range_oracle as O
+    from range_amd import load_model, synth
+    from range_amd.save import save_embeddings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=rbank, beta=0.5, shards=world)
+        assert m.row_range == ((N * rank) // world, (N * (rank + 1)) // world) and m.engine.n_rows == N // world
+        obank = O.prep_bank(*_bank_arrays())
+        w = synth.make_encoder_weights(L, H, 256, 2, SEED)
+        vmin, vmax = float(obank.values.min()), float(obank.values.max())
+        # ---- C4 shape: 100 000 queries over the two ranks (one more on rank 1: ragged), pole to pole
+        B = 50_000 + rank
+        q = synth.make_queries(B, seed=70 + rank, lat_max=90.0)
+        x = torch.from_numpy(q).to("cuda:0")
+        m.sharded.scan_chunk = 16384                      # 8 192 queries per rank and step
+        out = m(x, local=True, return_device=True)
+        assert out.shape == (B, 1280) and bool(torch.isfinite(out).all())
+        assert m.engine.kept_queries() > 0               # pass 2 ran on the kept logits of the shard
+        assert float((out[:, 0] - 1.0).abs().max()) < 1e-5 and float((out[:, 1] + 2.5).abs().max()) < 2.5e-5
+        assert float(out[:, :1024].max()) <= vmax and float(out[:, :1024].min()) >= vmin
+        assert float((out[:, 1024:].norm(dim=1) - 1.0).abs().max()) < 1e-12
+        idx = np.sort(np.random.default_rng(rank).choice(B, 256, replace=False))
+        _sample_check(out[torch.from_numpy(idx).cuda()].cpu().numpy()[None], q[idx], obank, w, (0.5,))
+        # global top-16 of the sample: one all-gather of the shards' candidates
+        tv, ti = m.topk(x[torch.from_numpy(idx).cuda()], 16, local=True)
+        e = out[torch.from_numpy(idx).cuda(), 1024:].cpu().numpy()
+        rv, ri = O.topk64(O.logits64(e, q[idx], obank)[0], 16)
+        bad = np.nonzero((ti.cpu().numpy() != ri).any(axis=1))[0]
+        assert len(bad) <= 1
+        np.testing.assert_allclose(tv.cpu().numpy(), rv, rtol=0, atol=3e-7)
+        del out
+        # ---- C5 shape: the beta sweep over the full (sharded) bank
+        betas = (0.0, 0.25, 0.5, 0.75, 1.0)
+        Bs = 10_000
+        sw = m.sweep(x[:Bs], betas, local=True, return_device=True)
+        assert sw.shape == (5, Bs, 1280) and bool(torch.isfinite(sw).all())
+        plain = m(x[:Bs], local=True, return_device=True)
+        assert float((sw[2] - plain).abs().max()) < 2e-6          # beta = 0.5: the blend of two roundings
+        idx = np.sort(np.random.default_rng(10 + rank).choice(Bs, 128, replace=False))
+        _sample_check(sw[:, torch.from_numpy(idx).cuda()].cpu().numpy(), q[idx], obank, w, betas)
+        del sw, plain
+        # ---- drop-in semantics: the same batch on every rank, the full result on every rank
+        for Bf in (1001, 1):
+            qf = synth.make_queries(Bf, seed=5)
+            full = m(torch.from_numpy(qf))
+            assert isinstance(full, np.ndarray) and full.shape == (Bf, 1280) and full.dtype == np.float64
+            k = min(Bf, 64)
+            _sample_check(full[None, :k], qf[:k], obank, w, (0.5,))
+            if Bf > 1:
+                _sample_check(full[None, -k:], qf[-k:], obank, w, (0.5,))
+        # ---- save_embeddings over the sharded model (reference: range/utils/save.py:7-58): rank 0 writes
+        from argparse import Namespace
+        rng = np.random.default_rng(3)
+        def loader(n_batches, bs):
+            for i in range(n_batches):
+                n = bs if i + 1 < n_batches else bs - 37                 # ragged tail (save.py:24-37)
+                yield torch.from_numpy(synth.make_queries(n, seed=900 + i)), torch.arange(n, dtype=torch.float32)
+        a = Namespace(embeddings_dir=os.path.join(tmp, "emb"), location_model_name="RANGE+", task_name="t")
+        save_embeddings(a, loader(3, 500), loader(2, 300), m)
+        dist.barrier()
+        z = np.load(os.path.join(tmp, "emb", "RANGE+", "t_train.npz"))
+        assert z["embeddings"].shape == (1463, 1280) and z["coords"].shape == (1463, 2) and z["y"].shape == (1463,)
+        _sample_check(z["embeddings"][None, :32], z["coords"][:32], obank, w, (0.5,))
+        assert np.load(os.path.join(tmp, "emb", "RANGE+", "t_val.npz"))["embeddings"].shape == (563, 1280)
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_product_entry_at_c4_c5_shapes(tmp_path):
+    from range_amd import synth
+    from range_amd.bank import prepare_bank
+    from range_amd.bankfile import write_bankfile
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
+    rbank = write_bankfile(str(tmp_path / "large.rbank"), prepare_bank(*_bank_arrays()))
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_rank, args=(world, _free_port(), ck, rbank, str(tmp_path), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def test_load_model_shards_needs_a_process_group(tmp_path):
+    from range_amd import load_model, synth
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=10, hidden=64, seed=1)
+    db = synth.write_bank(str(tmp_path / "db.npz"), 300, seed=3)
+    with pytest.raises(RuntimeError, match="torch.distributed"):
+        load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, shards=2)
+    with pytest.raises(ValueError, match="shards="):
+        load_model("SatCLIP", pretrained_path=ck, device="cuda:0", shards=2)
