@@ -70,6 +70,11 @@ def parse():
                     help="query chunks of the sharded forward (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=4096,
                     help="queries of the same workload timed on the host for cpu_baseline (0=off)")
+    ap.add_argument("--sweep", default=None, nargs="?", const="0,0.25,0.5,0.75,1",
+                    help="BASELINE config 5: one step = the embeddings of the batch for EVERY beta of this "
+                         "comma-separated list (default 0,0.25,0.5,0.75,1): pass 1 once, two passes 2 (the "
+                         "semantic and the geographic retrieval), one blend + finalize per beta; the line's "
+                         "value counts queries x betas")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (scan roofline, host-contract rate, weak-mode leg)")
     return ap.parse_args()
@@ -271,13 +276,35 @@ def main():
         q_all = synth.make_queries(B * world, seed=7, lat_max=90.0)
         q_host = q_all[rank * B:(rank + 1) * B]
         x = torch.from_numpy(q_host).to(dev)
-        out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+        CH = 16384                                      # queries per engine call (LocationEncoder.chunk_size)
+        if betas is None:
+            out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+        else:
+            out = torch.empty((len(betas), B, 1280), dtype=torch.float64, device=dev)
 
         def step():
-            if not sharded:
-                eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+            if betas is None:
+                if not sharded:
+                    for lo in range(0, B, CH if B > 2 * CH else B):
+                        hi = min(B, lo + (CH if B > 2 * CH else B))
+                        eng.forward(x[lo:hi], _native.MODEL_RANGE_PLUS, a.beta, out=out[lo:hi])
+                else:
+                    model.embed(x, out=out, b_max=B)    # (one outer step up to 16 384 scanned queries)
+            elif not sharded:
+                # LocationEncoder.sweep: H and G once per chunk, one blend + finalize per beta
+                for lo in range(0, B, CH):
+                    e64, e32, xq = eng.encode(x[lo:lo + CH])
+                    st = eng.scan_stats(e32, xq, 12.0, 40.0, keep_logits=True)
+                    if eng.kept_queries() == e32.shape[0]:
+                        Hs = eng.attend_kept(0, xq, 12.0, 40.0, 1.0, st)
+                        Gs = eng.attend_kept(0, xq, 12.0, 40.0, 0.0, st)
+                    else:
+                        Hs = eng.attend(e32, xq, 12.0, 40.0, 1.0, st)
+                        Gs = eng.attend(e32, xq, 12.0, 40.0, 0.0, st)
+                    for j, b in enumerate(betas):
+                        out[j, lo:lo + e64.shape[0]] = eng.finalize(eng.blend(Gs, Hs, b), e64)
             else:
-                out.copy_(model(x))
+                model.embed_sweep(x, betas, out=out, b_max=B)
 
         for _ in range(warmup):
             step()
@@ -300,10 +327,11 @@ def main():
         eng.profile_enable(False)
         comm_ms = model.comm_timing(False) if model is not None else None
         assert prof["attend"][1] >= steps and prof["attend"][1] % steps == 0, (prof, steps)
-        assert bool(torch.isfinite(out).all())
+        assert bool(torch.isfinite(out[..., :8]).all()) and bool(torch.isfinite(out[..., -8:]).all())
         return {"B": B, "dt": dt, "prof": prof, "comm_ms": comm_ms, "q_host": q_host, "out": out,
                 "kept": eng.kept_queries() > 0, "geometry": eng.last_geometry()}
 
+    betas = None if a.sweep is None else [float(v) for v in a.sweep.split(",")]
     m = measure(a.scaling, a.steps, a.warmup)
     B, dt = m["B"], m["dt"]
 
@@ -316,20 +344,29 @@ def main():
         obank = O.prep_bank(*bank_arrays)
         idx = np.linspace(0, B - 1, num=min(64, B), dtype=np.int64)
         qs = m["q_host"][idx]
-        got = m["out"][torch.from_numpy(idx).to(dev)].cpu().numpy()
+        sel = torch.from_numpy(idx).to(dev)
+        got_all = (m["out"][sel] if betas is None else m["out"][:, sel]).cpu().numpy()
+        got = got_all if betas is None else got_all[len(betas) // 2]
+        beta_chk = a.beta if betas is None else betas[len(betas) // 2]
         # e-hat against the oracle fed with the same SH polynomials (CPU evaluation of the table;
         # queries run pole to pole, where the reference's polynomials are ill-conditioned and the
         # last bit of pow() shows: inside |lat| <= 45 the two agree to 1e-7), retrieval given e-hat
         e = O.encode(qs, weights, L, features=table.evaluate(qs))
         band = np.abs(qs[:, 1]) <= 45.0
         got_e = got[:, 1024:]
-        ref32 = O.retrieve(got_e, qs, obank, "RANGE+", a.beta)
-        ref64 = O.retrieve64(got_e, qs, obank, "RANGE+", a.beta)
+        ref32 = O.retrieve(got_e, qs, obank, "RANGE+", beta_chk)
+        ref64 = O.retrieve64(got_e, qs, obank, "RANGE+", beta_chk)
         parity = {"rows": int(idx.size),
                   "max_abs_vs_reference_f32_order": float(np.abs(got - ref32).max()),
                   "max_abs_vs_f64_oracle": float(np.abs(got[:, :1024] - ref64).max()),
                   "ehat_max_abs_lat_le_45": float(np.abs(got_e - e)[band].max()),
                   "ehat_max_abs_all_latitudes": float(np.abs(got_e - e).max())}
+        if betas is not None:      # every beta of the sweep against the float64 oracle
+            parity["sweep_max_abs_vs_f64_oracle"] = {
+                str(b): float(np.abs(got_all[j][:, :1024] - O.retrieve64(got_e, qs, obank, "RANGE+", b)).max())
+                for j, b in enumerate(betas)}
+            if not max(parity["sweep_max_abs_vs_f64_oracle"].values()) < 1e-4:
+                raise SystemExit(f"bench parity failed: {parity}")
         parity_rows = {"idx": idx, "exact": got[:, :1024].copy(), "ref64": ref64}
         if not parity["ehat_max_abs_lat_le_45"] < 1e-6:
             raise SystemExit(f"bench parity failed: {parity}")
@@ -338,13 +375,14 @@ def main():
 
     # ---- untimed extras
     weak = None
-    if world > 1 and a.scaling == "strong" and not a.no_extras:
+    default_workload = betas is None and a.queries == 10_000
+    if world > 1 and a.scaling == "strong" and not a.no_extras and default_workload:
         mw = measure("weak", a.steps, max(1, a.warmup))
         weak = {"value": mw["B"] * world * a.steps / mw["dt"], "ms_per_step": mw["dt"] / a.steps * 1e3,
                 "queries_per_gpu": mw["B"], "comm_ms_exposed_per_step":
                     None if mw["comm_ms"] is None else mw["comm_ms"] / a.steps}
     control = None
-    if world > 1 and sharded and a.scaling == "strong" and not a.no_extras:
+    if world > 1 and sharded and a.scaling == "strong" and not a.no_extras and default_workload:
         # the control experiment of SURVEY.md 8(e): the same batch with the whole bank on every GPU,
         # each rank embedding its own queries end to end - no collective on the data path.  What the
         # row-sharded figure loses against it is the price of the exchange (and of scanning all
@@ -372,7 +410,7 @@ def main():
     scan = None
     host_contract = None
     opt_in = None
-    if world == 1 and not sharded and not a.no_extras:
+    if world == 1 and not sharded and not a.no_extras and default_workload:
         scan = scan_roofline(eng, synth, torch, dev, N, bank)
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
         opt_in = opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev)
@@ -384,7 +422,8 @@ def main():
         launches_per_step = att_n // a.steps
         # row-sharded: every rank attends all queries (in chunks); replicated bank: only its own
         q_scanned = B * (world if sharded else 1)
-        q_per_launch = q_scanned // launches_per_step
+        # (the sweep runs pass 2 twice per query: the semantic and the geographic retrieval)
+        q_per_launch = q_scanned * (2 if betas is not None else 1) // launches_per_step
         att_avg_ms = att_ms / att_n
         kept = m["kept"]     # which pass 2 ran: on the logits pass 1 kept (default) or recomputing
         flops = q_per_launch * n_local * (FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND)
@@ -402,19 +441,22 @@ def main():
         step_s = dt / a.steps
         st_flops = q_scanned * n_local * FLOP_PAIR_STATS
         en_flops = B * 2 * (L * L * H + H * H + 256 * H)
-        executed = (q_scanned * n_local * ((FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND)
+        executed = (q_scanned * n_local * ((FLOP_PAIR_ATTEND_KEPT if kept else FLOP_PAIR_ATTEND) * (2 if betas else 1)
                                            + FLOP_PAIR_STATS) + en_flops)
-        total_q = B * world * a.steps
+        n_out = 1 if betas is None else len(betas)
+        total_q = B * world * a.steps * n_out
         per_gpu = "in total" if a.scaling == "strong" else "per GPU"
         res = {
-            "metric": "geo-embeddings/sec (10k-query batch, range_db_large)",
+            "metric": ("geo-embeddings/sec (10k-query batch, range_db_large)" if default_workload and a.bank == "range_db_large"
+                       else f"geo-embeddings/sec ({a.queries}-query batch, {a.bank}"
+                            + (f", beta sweep x{n_out}: queries x betas per second)" if betas else ")")),
             "value": total_q / dt,
             "unit": "geo-embeddings/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RANGE+ beta={a.beta}, SatCLIP-L40 encoder (H={H}, synthetic "
+            "config": {"workload": f"RANGE+ {'beta sweep ' + a.sweep if betas else 'beta=' + str(a.beta)}, SatCLIP-L40 encoder (H={H}, synthetic "
                                    f"weights), {a.bank} (synthetic, N={N}), {a.queries} queries "
                                    f"{per_gpu} per step ({B} per GPU), device-resident in/out",
                        "bank_rows": N, "queries_total": B * world, "queries_per_gpu": B, "hidden": H,
@@ -445,7 +487,7 @@ def main():
                            "achieved_tflops": achieved, "frac": achieved / PEAK_F32_MATRIX_TFLOPS},
                 "other_ms_per_step": step_s * 1e3 - (en_ms + st_ms + att_ms) / a.steps},
             "executed_tflops": executed / step_s / 1e12,
-            "reference_equivalent_tflops": B * world * N * FLOP_PAIR_REFERENCE / step_s / 1e12,
+            "reference_equivalent_tflops": B * world * n_out * N * FLOP_PAIR_REFERENCE / step_s / 1e12,
             "parity_max_abs": parity["max_abs_vs_reference_f32_order"],
             "parity": parity,
         }

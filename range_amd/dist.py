@@ -240,7 +240,7 @@ class ShardedRange:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
-    def _steps(self, lonlat: torch.Tensor, chunk: Optional[int]):
+    def _steps(self, lonlat: torch.Tensor, chunk: Optional[int], b_max: Optional[int] = None):
         """Outer steps of a ragged job: every rank brings its OWN number of queries (0 allowed); the
         ranks agree on the largest count (one scalar all-reduce), walk it in steps of ``chunk``
         queries per rank and pad their share of a step to the step's size with copies of a dummy
@@ -249,7 +249,8 @@ class ShardedRange:
         if lonlat.dim() != 2 or lonlat.shape[1] != 2:
             raise ValueError(f"lonlat must be (B,2) (lon,lat) degrees, got {tuple(lonlat.shape)}")
         B = lonlat.shape[0]
-        b_max = self._max_over_ranks(B, lonlat.device)
+        if b_max is None:      # (a caller that knows every rank brings the same count passes it: no collective)
+            b_max = self._max_over_ranks(B, lonlat.device)
         if chunk is None:
             chunk = max(64, self.scan_chunk // self.world // 64 * 64)
         chunk = max(1, int(chunk))
@@ -266,28 +267,31 @@ class ShardedRange:
 
     @torch.no_grad()
     def embed(self, lonlat: torch.Tensor, chunk: Optional[int] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, b_max: Optional[int] = None) -> torch.Tensor:
         """The product entry of the row-sharded path: this rank's (B,2) queries -> its (B,1280)
         float64 embeddings (device tensor), for ANY per-rank B (ragged across ranks, zero on some),
         in outer steps of ``chunk`` queries per rank (default: ``scan_chunk`` scanned queries per
-        step).  Collective: every rank of the group must call it."""
+        step).  Collective: every rank of the group must call it.  ``b_max``: the largest per-rank
+        count, when the caller knows it (equal counts: ``b_max=B``) - saves the scalar all-reduce."""
         B = lonlat.shape[0]
         if out is None:
             out = torch.empty((B, 1280), dtype=torch.float64, device=lonlat.device)
-        for lo, n_own, q in self._steps(lonlat, chunk):
+        for lo, n_own, q in self._steps(lonlat, chunk, b_max):
             res = self.forward(q)
             if n_own:
                 out[lo:lo + n_own] = res[:n_own]
         return out
 
     @torch.no_grad()
-    def embed_sweep(self, lonlat: torch.Tensor, betas, chunk: Optional[int] = None) -> torch.Tensor:
+    def embed_sweep(self, lonlat: torch.Tensor, betas, chunk: Optional[int] = None,
+                    out: Optional[torch.Tensor] = None, b_max: Optional[int] = None) -> torch.Tensor:
         """``embed`` for several beta values at once (one pass 1 and two passes 2 per step whatever
         the number of betas): (len(betas), B, 1280) float64 on the device."""
         betas = [float(b) for b in betas]
         B = lonlat.shape[0]
-        out = torch.empty((len(betas), B, 1280), dtype=torch.float64, device=lonlat.device)
-        for lo, n_own, q in self._steps(lonlat, chunk):
+        if out is None:
+            out = torch.empty((len(betas), B, 1280), dtype=torch.float64, device=lonlat.device)
+        for lo, n_own, q in self._steps(lonlat, chunk, b_max):
             res = self.sweep(q, betas)
             if n_own:
                 out[:, lo:lo + n_own] = res[:, :n_own]

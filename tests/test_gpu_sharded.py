@@ -92,7 +92,11 @@ def _rank(rank, world, port, ck, rbank, tmp, ret):
         sw = m.sweep(x[:Bs], betas, local=True, return_device=True)
         assert sw.shape == (5, Bs, 1280) and bool(torch.isfinite(sw).all())
         plain = m(x[:Bs], local=True, return_device=True)
-        assert float((sw[2] - plain).abs().max()) < 2e-6          # beta = 0.5: the blend of two roundings
+        # beta = 0.5: the blend of H and G (range.py:238, float32) against the forward's one combined
+        # weight (planted constant columns: float32 sums of 10^5 same-sign terms, formed once per
+        # retrieval here and once for the combined weight there; other columns 1e-7)
+        d = (sw[2] - plain).abs()
+        assert float(d[:, 2:].max()) < 2e-6 and float(d[:, :2].max()) < 5e-5
         idx = np.sort(np.random.default_rng(10 + rank).choice(Bs, 128, replace=False))
         _sample_check(sw[:, torch.from_numpy(idx).cuda()].cpu().numpy(), q[idx], obank, w, betas)
         del sw, plain
