@@ -1294,19 +1294,45 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     if (rc) return rc;
     const bool kept = c->kept_B == B;
 
-    // Pass 2 runs in `n_parts` launches over consecutive query ranges (boundaries on query
-    // tiles): the device->host copy and the host fill of a part overlap pass 2 of the next, so
-    // only the last part's copy is exposed.  (More, smaller launches fill the chip's rounds less
-    // well - about 1 % per extra launch at this size - so large batches take 2 parts, not 8.)
-    const int n_parts = B >= 4096 ? 2 : 1;
+    // Pass 2 runs in a few launches over consecutive query ranges (boundaries on query tiles): the
+    // device->host copy and the host fill of a part overlap pass 2 of the next, so only the LAST
+    // part's copy and fill are exposed - and the parts SHRINK: the rest, 4 096, 1 024 queries.  The
+    // copy pipeline (DMA 0.2 ms, host fill 0.35 ms per 1 000 queries) is four times faster than pass 2
+    // (1.46 ms per 1 000 queries against range_db_large), so a part four times the size of its
+    // successor is drained while the successor computes; the last 1 024 queries leave ~0.3 ms
+    // exposed (two equal halves left 1.4 ms).  Part sizes matter on the GPU side: the split count of
+    // pass 2 is chosen per launch so that its workgroups fill whole rounds of the chip, and 16 query
+    // tiles x 16 bank splits are exactly one round - measured for 10 000 queries (tools/host_parts.py,
+    // pass 2 in one launch 14.65 ms): parts (4 096, 1 024) 14.80 ms, (1 024) 14.85, (2 048, 512) 15.42.
+    std::vector<int64_t> cuts{0};
+    if (B >= 4096) {
+        // RANGE_HOST_PARTS="2048,512": sizes of the parts behind the first (tuning)
+        std::vector<int64_t> tail{4096, 1024};
+        if (const char* e = std::getenv("RANGE_HOST_PARTS")) {
+            tail.clear();
+            for (const char* q = e; *q;) {
+                char* end = nullptr;
+                const long v = std::strtol(q, &end, 10);
+                if (end == q) break;
+                if (v > 0) tail.push_back(v);
+                q = *end ? end + 1 : end;
+            }
+        }
+        int64_t rest = 0;
+        for (auto v : tail) rest += v;
+        if (rest < B) {
+            int64_t at = B - rest;
+            for (auto v : tail) { cuts.push_back(at / QTILE * QTILE); at += v; }
+        }
+    }
+    cuts.push_back(B);
     constexpr int64_t SLAB = 1024;
     struct Slab { int64_t q0, nq; hipEvent_t fin, cop; };
     std::vector<Slab> slabs;
     auto give_back = [&]() { for (auto& sl : slabs) { c->ev_pool.push_back(sl.fin); c->ev_pool.push_back(sl.cop); } };
     hipError_t e = hipSuccess;
-    for (int part = 0; part < n_parts && e == hipSuccess; ++part) {
-        const int64_t p0 = ((B * part / n_parts) + QTILE / 2) / QTILE * QTILE;
-        const int64_t p1 = part + 1 == n_parts ? B : ((B * (part + 1) / n_parts) + QTILE / 2) / QTILE * QTILE;
+    for (size_t part = 0; part + 1 < cuts.size() && e == hipSuccess; ++part) {
+        const int64_t p0 = cuts[part], p1 = cuts[part + 1];
         if (p1 <= p0) continue;
         int n_splits = 0;
         rc = attend_impl(c, c->ws_ehat32.p + p0 * 256, c->ws_xq.p + p0 * 4, p1 - p0, tau_sem, tau_geo, bt,
@@ -1314,8 +1340,11 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         if (rc) { (void)hipDeviceSynchronize(); give_back(); return rc; }
         // finalize per slab (the split slabs of this part are overwritten by the next part's pass 2,
         // which is behind these kernels in stream order)
-        for (int64_t q0 = p0; q0 < p1 && e == hipSuccess; q0 += SLAB) {
-            Slab sl{q0, std::min<int64_t>(SLAB, p1 - q0), c->get_event(), c->get_event()};
+        // (the last part in slabs of 256 queries: its copies and fills are what the caller waits for,
+        // and they pipeline per slab)
+        const int64_t slab = part + 2 == cuts.size() && cuts.size() > 2 ? SLAB / 4 : SLAB;
+        for (int64_t q0 = p0; q0 < p1 && e == hipSuccess; q0 += slab) {
+            Slab sl{q0, std::min<int64_t>(slab, p1 - q0), c->get_event(), c->get_event()};
             slabs.push_back(sl);
             const int64_t n = sl.nq * 320;
             hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
