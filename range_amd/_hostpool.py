@@ -3,15 +3,28 @@
 ``model(x)`` hands the caller a host array per call (range/range.py:240).  A fresh 100 MB array
 costs first-touch page faults while it is filled and a page-table teardown (munmap) when the caller
 drops it - together 8 to 10 ms per 10 000 queries, a third of the GPU time of the batch.  The pool
-keeps the memory of results the caller has DROPPED and hands it out again: a result is a float64
-view of a pool-owned byte array; when the result object dies and nothing else references the byte
-array (a surviving view of the result would), the bytes go back on the free list instead of back
-to the OS.  Callers that keep every result (``save_embeddings`` collects them) simply never
-return anything: they get fresh arrays as before.
+keeps the memory of results the caller has DROPPED and hands it out again.
+
+Ownership is explicit (round 2 decided it from ``sys.getrefcount`` inside a finalizer - one
+interpreter change away from handing live memory out again): the pool owns plain memory blocks; a
+result is ``numpy.frombuffer`` over a per-result GUARD object (a ctypes array created
+``from_buffer`` of the block), so the result, every slice / transpose / reshape of it and every
+``torch.from_numpy`` tensor over it hold a reference chain to that guard - it is the ``base`` the
+views collapse to.  The block goes back on the free list from the guard's finalizer, i.e. only
+once the interpreter itself has found the guard unreachable: no reference counts are read, a view
+that outlives the result (in another thread, in a reference cycle, under a delayed garbage
+collector) keeps the memory out of the pool exactly as long as it lives.  Callers that keep every
+result (``save_embeddings`` collects them) never return anything and get fresh memory as before.
+
+What no ownership scheme in Python can see is a consumer holding a RAW POINTER into a result it has
+dropped (``arr.ctypes.data`` / ``__array_interface__`` borrowed by a C extension without a
+reference to the array).  The reference's arrays are not safe to use that way either (freed memory
+instead of recycled memory); ``RANGE_HOST_POOL=0`` in the environment turns the pool off.
 """
 from __future__ import annotations
 
-import sys
+import ctypes
+import os
 import threading
 import weakref
 from typing import Dict, List
@@ -19,54 +32,57 @@ from typing import Dict, List
 import numpy as np
 
 
+def _size_class(nbytes: int) -> int:
+    """Block capacity for a request: the next multiple of 1/8 of the enclosing power of two (at most
+    12.5 % over) - a bounded set of capacities, hence of ctypes guard types, whatever batch sizes a
+    serving loop sends."""
+    if nbytes <= 4096:
+        return 4096
+    step = 1 << max(12, nbytes.bit_length() - 4)
+    return (nbytes + step - 1) // step * step
+
+
 class HostResultPool:
-    #: free byte arrays kept per size, and in total bytes
+    #: free blocks kept per capacity, and in total bytes
     max_free_per_size = 2
     max_free_bytes = 1 << 30
 
-    def __init__(self):
-        self._free: Dict[int, List[np.ndarray]] = {}
+    def __init__(self, enabled: bool | None = None):
+        self._free: Dict[int, List[bytearray]] = {}
         self._free_bytes = 0
         self._lock = threading.Lock()
-        # reference count of the byte array seen inside the finalizer when NOTHING else holds it
-        # (the finalizer's argument tuple, the call's own references): measured once through the
-        # very same call path, so that it is right for this interpreter
-        self._baseline = None
-        probe = np.empty(8, dtype=np.uint8)
-        view = probe.view(np.float64)
-        weakref.finalize(view, self._give_back, probe)
-        del probe, view
-        assert self._baseline is not None
+        self.enabled = (os.environ.get("RANGE_HOST_POOL", "1") != "0") if enabled is None else enabled
 
     def take(self, rows: int, cols: int) -> np.ndarray:
-        """A C-contiguous float64 array (rows, cols): recycled memory when some is free."""
+        """A C-contiguous, writeable float64 array (rows, cols): recycled memory when some is free."""
         nbytes = rows * cols * 8
-        buf = None
+        if not self.enabled or nbytes == 0:
+            return np.empty((rows, cols), dtype=np.float64)
+        cap = _size_class(nbytes)
+        block = None
         with self._lock:
-            lst = self._free.get(nbytes)
+            lst = self._free.get(cap)
             if lst:
-                buf = lst.pop()
-                self._free_bytes -= nbytes
-        if buf is None:
-            buf = np.empty(nbytes, dtype=np.uint8)
-        out = buf.view(np.float64).reshape(rows, cols)      # out.base is buf (views collapse to the owner)
-        weakref.finalize(out, self._give_back, buf)
+                block = lst.pop()
+                self._free_bytes -= cap
+        if block is None:
+            block = bytearray(cap)              # (zero pages: mapped on first touch, like np.empty)
+        guard = (ctypes.c_ubyte * cap).from_buffer(block)
+        fin = weakref.finalize(guard, self._give_back, block)
+        fin.atexit = False
+        out = np.frombuffer(guard, dtype=np.float64, count=rows * cols).reshape(rows, cols)
+        del guard                               # (only the array and its views hold it now)
         return out
 
-    def _give_back(self, buf: np.ndarray) -> None:
-        # anything beyond the baseline count is a view of the dropped result that is still alive:
-        # its memory must not be handed out again
-        n = sys.getrefcount(buf)
-        if self._baseline is None:
-            self._baseline = n
-            return
-        if n > self._baseline or sys.is_finalizing():
-            return
+    def _give_back(self, block: bytearray) -> None:
+        # called by the interpreter once the guard of a result is unreachable: nothing can see the
+        # block's memory through numpy any more
+        cap = len(block)
         with self._lock:
-            lst = self._free.setdefault(buf.nbytes, [])
-            if len(lst) < self.max_free_per_size and self._free_bytes + buf.nbytes <= self.max_free_bytes:
-                lst.append(buf)
-                self._free_bytes += buf.nbytes
+            lst = self._free.setdefault(cap, [])
+            if len(lst) < self.max_free_per_size and self._free_bytes + cap <= self.max_free_bytes:
+                lst.append(block)
+                self._free_bytes += cap
 
 
 POOL = HostResultPool()

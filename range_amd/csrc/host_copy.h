@@ -33,8 +33,12 @@ class HostCopyPool {
     }
     int size() const { return n_; }
 
-    // runs job(t, size()) on all workers and returns when every one has finished
+    // runs job(t, size()) on all workers and returns when every one has finished.  One job at a
+    // time: callers from several threads (ctypes drops the GIL around the library's calls) queue
+    // up on call_mu_ - without it a second caller would overwrite job_ / pending_ / generation_
+    // under the first one's wait (a partially filled array, or a deadlock).
     void run(const std::function<void(int, int)>& job) {
+        std::lock_guard<std::mutex> one_caller(call_mu_);
         std::unique_lock<std::mutex> g(mu_);
         job_ = &job;
         pending_ = n_;
@@ -91,7 +95,7 @@ class HostCopyPool {
     }
     const int n_;
     std::vector<std::thread> workers_;
-    std::mutex mu_;
+    std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(int, int)>* job_ = nullptr;
     uint64_t generation_ = 0;

@@ -113,6 +113,25 @@ static void test_copy_pool() {
         for (int rep = 0; rep < 50; ++rep) pool.run([&](int t, int n) { CHECK(n == threads); ++hits[t]; });
         for (int v : hits) CHECK(v == 50);
     }
+    // several callers at once on ONE pool (Python threads around ctypes calls): every copy complete
+    {
+        HostCopyPool pool(4);
+        const size_t bytes = ((size_t)3 << 20) + 5;
+        std::vector<std::thread> callers;
+        std::vector<int> ok(6, 0);
+        for (int c = 0; c < 6; ++c)
+            callers.emplace_back([&, c] {
+                std::vector<unsigned char> src(bytes, (unsigned char)(c + 1)), dst(bytes, 0);
+                for (int rep = 0; rep < 8; ++rep) {
+                    std::fill(dst.begin(), dst.end(), 0);
+                    pool.copy(dst.data(), src.data(), bytes);
+                    if (std::memcmp(dst.data(), src.data(), bytes) != 0) return;
+                }
+                ok[c] = 1;
+            });
+        for (auto& t : callers) t.join();
+        for (int v : ok) CHECK(v == 1);
+    }
 }
 
 int main() {

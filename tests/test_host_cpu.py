@@ -222,14 +222,21 @@ def test_checkpoint_with_uninstalled_helper_classes(tmp_path):
 
 def test_host_result_pool_recycles_only_unreferenced_memory():
     """range_amd/_hostpool.py: the memory of a dropped result is handed out again, but never
-    while a view of that result is alive (it would be overwritten under the caller)."""
-    from range_amd._hostpool import HostResultPool
-    P = HostResultPool()
+    while a view of that result is alive (it would be overwritten under the caller).  Ownership is
+    the interpreter's own reachability of a per-result guard object - no reference counts are
+    read - so the adversarial cases hold by construction: a view that outlives the result in
+    another thread, a torch tensor over it, a view parked in a reference cycle until the garbage
+    collector runs (what a delayed collector - PyPy, a free-threaded build - does to every object)."""
+    import gc
+    import threading
+    from range_amd._hostpool import HostResultPool, _size_class
+    P = HostResultPool(enabled=True)
+    cap = _size_class(64 * 1280 * 8)
     a = P.take(64, 1280)
     assert a.dtype == np.float64 and a.shape == (64, 1280) and a.flags.c_contiguous and a.flags.writeable
     addr = a.ctypes.data
     del a
-    assert P._free_bytes == 64 * 1280 * 8
+    assert P._free_bytes == cap
     b = P.take(64, 1280)
     assert b.ctypes.data == addr and P._free_bytes == 0        # recycled
     b[:] = 3.0
@@ -243,10 +250,62 @@ def test_host_result_pool_recycles_only_unreferenced_memory():
     del c
     assert P._free_bytes == 0
     del t, v
-    # bounded: at most max_free_per_size arrays of one size are kept
-    arrs = [P.take(8, 1280) for _ in range(5)]
+    assert P._free_bytes == 2 * cap
+    # a torch tensor over a dropped result
+    d = P.take(64, 1280)
+    d[:] = 7.0
+    tt = torch.from_numpy(d)[5]
+    del d
+    e = P.take(64, 1280); e[:] = 9.0
+    f = P.take(64, 1280); f[:] = 11.0
+    assert float(tt.sum()) == 7.0 * 1280
+    del tt, e, f
+    # a view handed to another thread that is still running when the result is dropped
+    g = P.take(64, 1280)
+    g[:] = 13.0
+    seen, go = [], threading.Event()
+
+    def worker(view):
+        go.wait()
+        seen.append(float(view.sum()))
+
+    th = threading.Thread(target=worker, args=(g[10:20].reshape(-1),))
+    th.start()
+    del g
+    others = [P.take(64, 1280) for _ in range(3)]
+    for o in others:
+        o[:] = -1.0
+    go.set()
+    th.join()
+    assert seen == [13.0 * 10 * 1280]
+    del others, th
+    # a view in a reference cycle: unreachable, but only the garbage collector can tell
+    gc.collect()
+    gc.disable()
+    try:
+        free0 = P._free_bytes
+        h = P.take(32, 1280)
+        cyc = {"view": h[3:5]}
+        cyc["self"] = cyc
+        del h, cyc
+        assert P._free_bytes == free0                                      # (a fresh block) still out of the pool
+        gc.collect()
+        assert P._free_bytes == free0 + _size_class(32 * 1280 * 8)         # in it once collected
+    finally:
+        gc.enable()
+    # bounded: at most max_free_per_size blocks of one capacity are kept; capacities come from a
+    # bounded set of size classes whatever the batch sizes
+    P2 = HostResultPool(enabled=True)
+    arrs = [P2.take(8, 1280) for _ in range(5)]
     del arrs
-    assert P._free_bytes == P.max_free_per_size * 8 * 1280 * 8
+    assert P2._free_bytes == P2.max_free_per_size * _size_class(8 * 1280 * 8)
+    assert len({_size_class(n * 10240) for n in range(1, 20000)}) < 120
+    assert all(_size_class(n) >= n and _size_class(n) <= max(4096, n * 1.125 + 1) for n in (1, 70_000, 10 ** 6, 10 ** 8 + 7))
+    # RANGE_HOST_POOL=0: plain fresh arrays
+    off = HostResultPool(enabled=False)
+    x = off.take(4, 1280)
+    del x
+    assert off._free_bytes == 0
 
 
 @pytest.mark.parametrize("flags", [["-fsanitize=address,undefined", "-fno-sanitize-recover=all"],
