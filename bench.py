@@ -62,10 +62,12 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded (torch.distributed) path even with one rank "
                          "(rehearsal of the N>1 code path on a 1-GPU box)")
-    ap.add_argument("--layout", default="row-sharded", choices=["row-sharded", "query-sharded"],
-                    help="N>1: row-sharded bank with the RCCL exchange (north-star layout, default) or "
-                         "the control: the whole bank on every GPU, each rank embeds its own queries, "
-                         "no collective on the data path")
+    ap.add_argument("--layout", default="row-sharded",
+                    help="N>1: 'row-sharded' (north-star layout, default: the bank row-sharded over all N ranks, "
+                         "RCCL exchange), 'query-sharded' (the control: the whole bank on every GPU, each rank "
+                         "embeds its own queries, no collective on the data path) or 'RxQ' (2-D: the bank "
+                         "row-sharded over groups of R ranks, Q = N/R groups each serving its own queries, "
+                         "e.g. 2x4; Rx1 = row-sharded, 1xQ = query-sharded)")
     ap.add_argument("--shard-chunks", type=int, default=0,
                     help="query chunks of the sharded forward (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=4096,
@@ -229,11 +231,23 @@ def main():
     dev = torch.device("cuda", local if backend == "nccl" else local % n_dev)
     torch.cuda.set_device(dev)
     dist = None
-    replicated = world > 1 and a.layout == "query-sharded"
+    import re as _re
+    mm = _re.fullmatch(r"(\d+)x(\d+)", a.layout)
+    if mm:
+        row_shards = int(mm.group(1))
+        if row_shards * int(mm.group(2)) != world:
+            raise SystemExit(f"--layout {a.layout} does not multiply to --gpus {world}")
+    elif a.layout == "query-sharded":
+        row_shards = 1
+    elif a.layout == "row-sharded":
+        row_shards = world
+    else:
+        raise SystemExit(f"unknown --layout {a.layout!r}")
+    replicated = world > 1 and row_shards == 1
     sharded = (world > 1 and not replicated) or a.force_sharded
     if world > 1 or sharded:
         import torch.distributed as dist
-        from range_amd.dist import ShardedRange, init_from_env, shard_rows
+        from range_amd.dist import ShardedRange, init_from_env, make_layout, shard_rows
         init_from_env(backend)
 
     L, H = 40, a.hidden
@@ -251,11 +265,12 @@ def main():
         eng.set_bank(bank.keys, bank.values, bank.xyz, 0)
         n_local = N
     else:
-        r0, r1 = shard_rows(N, world, rank)
+        shard_group, shard_index, _ = make_layout(row_shards)
+        r0, r1 = shard_rows(N, row_shards, shard_index)
         sh = bank.rows(r0, r1)
         eng.set_bank(sh.keys, sh.values, sh.xyz, r0)
         n_local = r1 - r0
-        model = ShardedRange(eng, "RANGE+", a.beta, n_chunks=a.shard_chunks or None)
+        model = ShardedRange(eng, "RANGE+", a.beta, group=shard_group, n_chunks=a.shard_chunks or None)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -421,7 +436,7 @@ def main():
         en_ms, en_n = m["prof"]["encoder"]
         launches_per_step = att_n // a.steps
         # row-sharded: every rank attends all queries (in chunks); replicated bank: only its own
-        q_scanned = B * (world if sharded else 1)
+        q_scanned = B * (row_shards if sharded else 1)
         # (the sweep runs pass 2 twice per query: the semantic and the geographic retrieval)
         q_per_launch = q_scanned * (2 if betas is not None else 1) // launches_per_step
         att_avg_ms = att_ms / att_n
@@ -461,7 +476,8 @@ def main():
                                    f"{per_gpu} per step ({B} per GPU), device-resident in/out",
                        "bank_rows": N, "queries_total": B * world, "queries_per_gpu": B, "hidden": H,
                        "bank_layout": ("single GPU" if world == 1 and not sharded else
-                                       f"row-sharded x{world}" if sharded else
+                                       (f"row-sharded x{world}" if row_shards == world else
+                                        f"2-D: row-sharded x{row_shards}, {world // row_shards} query groups") if sharded else
                                        f"replicated x{world} (query-sharded control)"),
                        "bank_rows_per_gpu": n_local, "query_tiles": qt, "bank_splits": ns},
             "roofline": {"kernel": ("attend_stored_kernel<GEO> (pass 2 on kept logits: w@V, f32 MFMA)"
@@ -494,6 +510,7 @@ def main():
         if dist is not None:
             res["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "layout": a.layout if world > 1 else "row-sharded (forced, one rank)",
+                           "row_shards": row_shards if sharded else 1, "query_groups": world // row_shards if sharded else world,
                            "comm_ms_exposed_per_step":
                                None if m["comm_ms"] is None else m["comm_ms"] / a.steps}
         if weak is not None:

@@ -378,6 +378,30 @@ class ShardedRange:
         return self.engine.merge_topk(vals, idxs)
 
 
+def make_layout(row_shards: int, group=None):
+    """The 2-D layout R x Q of a W-rank job (W = R Q): the bank is row-sharded over R ranks - a SHARD
+    GROUP: ranks g R .. g R + R - 1 - and there are Q such groups, each a full copy of the bank serving
+    its own queries.  R = W is the north-star layout (one group, every collective spans the node);
+    R = 1 is the query-sharded control (no collective on the data path); in between the collectives
+    span R ranks only, the all-to-all is (R - 1) transfers per rank, a shard has N / R rows (pass 2
+    keeps its whole-round efficiency on bigger shards) and a rank scans R times its own queries
+    instead of W times.  Every rank of `group` must call this (the sub-groups are created
+    collectively).  Returns (shard_group, shard_index, query_group_index)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    R = int(row_shards)
+    if R < 1 or world % R:
+        raise ValueError(f"row_shards={row_shards} does not divide the {world} ranks")
+    if R == world:
+        return group, rank, 0
+    ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+    mine = None
+    for g in range(world // R):
+        sub = dist.new_group(ranks=ranks[g * R:(g + 1) * R])
+        if rank // R == g:
+            mine = sub
+    return mine, rank % R, rank // R
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun)."""
     import os

@@ -29,7 +29,9 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
             ``torch.distributed`` job (one process per GPU, RCCL); every rank calls ``load_model``
             with the same arguments and ``device`` = its own GPU and gets a model with the same
             call contract (``range_amd.range.ShardedLocationEncoder``); ``group`` - the process
-            group to shard over (default: the world).
+            group to shard over (default: the world); ``row_shards`` - R < W: the 2-D layout, the
+            bank row-sharded over groups of R ranks, W / R groups each serving its own queries
+            (``range_amd.dist.make_layout``; default R = W).
     """
     if pretrained_path is None:
         raise ValueError("Please provide the pretrained model path.")      # load_model.py:31-32
@@ -42,7 +44,7 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
         beta = None
     args = Namespace(location_model_name=model_name, pretrained_path=pretrained_path,
                      device=device, range_db=db_path, beta=beta)           # :45-46
-    for opt in ("sh_eval", "sh_source", "pv_mode", "shards"):
+    for opt in ("sh_eval", "sh_source", "pv_mode", "shards", "row_shards"):
         if opt in kwargs:
             setattr(args, opt, kwargs[opt])
     if kwargs.get("shards"):

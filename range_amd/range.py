@@ -275,7 +275,7 @@ class ShardedLocationEncoder(nn.Module):
     def __init__(self, args, group=None):
         super().__init__()
         import torch.distributed as dist
-        from .dist import ShardedRange, shard_rows
+        from .dist import ShardedRange, make_layout, shard_rows
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("load_model(..., shards=W) needs an initialised torch.distributed job "
                                "(torchrun --nproc-per-node W; range_amd.dist.init_from_env())")
@@ -303,14 +303,18 @@ class ShardedLocationEncoder(nn.Module):
         self.location_feature_dim = 1024 + 256                           # :86
         self.encoder_params = enc
         self.n_bank_rows = bank.n_rows
-        if self.n_bank_rows < self.world:
-            raise ValueError(f"bank of {self.n_bank_rows} rows cannot be sharded over {self.world} ranks")
-        self.row_range = shard_rows(bank.n_rows, self.world, self.rank)
+        # 2-D layout (dist.make_layout): the bank row-sharded over `row_shards` ranks (default: all of
+        # them), world / row_shards such groups each serving its own queries
+        self.row_shards = int(getattr(args, "row_shards", None) or self.world)
+        self.shard_group, shard_index, self.query_group = make_layout(self.row_shards, group)
+        if self.n_bank_rows < self.row_shards:
+            raise ValueError(f"bank of {self.n_bank_rows} rows cannot be sharded over {self.row_shards} ranks")
+        self.row_range = shard_rows(bank.n_rows, self.row_shards, shard_index)
         self._device = _device_of(args.device)
         self.engine = make_engine(enc, bank.rows(*self.row_range), self._device, row_offset=self.row_range[0],
                                   sh_eval=getattr(args, "sh_eval", None), sh_source=getattr(args, "sh_source", None),
                                   pv_mode=getattr(args, "pv_mode", None))
-        self.sharded = ShardedRange(self.engine, self.location_model_name, args.beta, group=group)
+        self.sharded = ShardedRange(self.engine, self.location_model_name, args.beta, group=self.shard_group)
         self.eval()
 
     def _coords(self, coords) -> torch.Tensor:

@@ -213,3 +213,43 @@ def test_sharded_embed_ragged_batches_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_ragged_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def _layout_worker(rank, world, port, R, ret):
+    """2-D layout R x Q (dist.make_layout): the bank row-sharded inside groups of R ranks, the groups
+    independent; every rank's own queries against the WHOLE bank."""
+    from range_amd.dist import make_layout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, L, H, B = 601, 10, 64, 70 + rank
+        locs, vals, keys = synth.make_bank(N, 11)
+        full = O.prep_bank(locs, vals, keys)
+        group, si, qg = make_layout(R)
+        assert (si, qg) == (rank % R, rank // R) and (dist.get_world_size(group) == R)
+        r0, r1 = shard_rows(N, R, si)
+        shard = O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1])
+        w = synth.make_encoder_weights(L, H, 256, 2, 5)
+        model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5, group=group)
+        assert model.world == R and model.rank == si
+        q = synth.make_queries(B, seed=400 + rank)
+        out = model.embed(torch.from_numpy(q), chunk=64).numpy()
+        err = float(np.abs(out - O.forward(q, w, L, full, "RANGE+", 0.5)).max())
+        assert out.shape == (B, 1280) and err < 1e-5, err
+        tv, ti = model.embed_topk(torch.from_numpy(q), 8)
+        s, _ = O.logits64(O.encode(q, w, L), q, full)
+        assert np.array_equal(ti.numpy(), O.topk64(s, 8)[1])
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_two_dimensional_layout_gloo(R):
+    world = 4
+    ret = mp.Manager().dict()
+    mp.spawn(_layout_worker, args=(world, _free_port(), R, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)

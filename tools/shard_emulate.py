@@ -10,7 +10,10 @@ communication, for both scaling modes of bench.py:
 The time of this against the single-GPU step bounds the scaling efficiency from above (the
 exchange - all-gather of 1 040 B per query, all-reduce of 8 B per query, all-to-all of 4 KB per
 query - comes on top; DESIGN.md section 6 prices it).
-Usage: python tools/shard_emulate.py [--json] [--chunks k] [N ...]"""
+--layouts W: the strong mode for every 2-D layout R x Q of W ranks (range_amd.dist.make_layout: the bank
+row-sharded over R ranks, Q = W / R such groups each serving its own queries): a rank holds 100 000 / R
+rows, encodes 10 000 / W queries and scans the 10 000 / Q queries of its group.
+Usage: python tools/shard_emulate.py [--json] [--chunks k] [--layouts W] [N ...]"""
 import json
 import os
 import sys
@@ -29,12 +32,19 @@ as_json = "--json" in sys.argv
 FORCE_CHUNKS = int(sys.argv[sys.argv.index("--chunks") + 1]) if "--chunks" in sys.argv else 0
 if FORCE_CHUNKS:
     del sys.argv[sys.argv.index("--chunks"):sys.argv.index("--chunks") + 2]
+LAYOUTS_W = int(sys.argv[sys.argv.index("--layouts") + 1]) if "--layouts" in sys.argv else 0
+if LAYOUTS_W:
+    del sys.argv[sys.argv.index("--layouts"):sys.argv.index("--layouts") + 2]
 worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
 base = {}
-for mode in ("strong", "weak"):
-    for W in worlds:
+# (mode, ranks in total, row shards R): a rank scans R x its own queries against 100 000 / R rows
+cases = [(mode, W, W) for mode in ("strong", "weak") for W in worlds]
+if LAYOUTS_W:
+    cases = [("strong", 1, 1)] + [("strong", LAYOUTS_W, R) for R in (8, 4, 2, 1) if R <= LAYOUTS_W and LAYOUTS_W % R == 0]
+for mode, WT, W in cases:                                       # W = ranks of a shard group from here on
+    if True:
         n = 100000 // W
-        B = 10000 // W if mode == "strong" else 10000          # this rank's own queries
+        B = 10000 // WT if mode == "strong" else 10000         # this rank's own queries
         eng = _native.HipEngine(dev)
         eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
                         [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]], sh_table=TABLE)
@@ -71,14 +81,15 @@ for mode in ("strong", "weak"):
         ms = a.elapsed_time(b) / 5
         k = {nm: round(eng.profile_read(i)[0] / 5, 3) for i, nm in enumerate(["encoder", "scan_stats", "attend"])}
         qt, ns = eng.last_geometry()
-        if W == 1:
+        if WT == 1:
             base[mode] = ms
-        total_q = B * W
-        rec = {"mode": mode, "n_gpus": W, "ms_per_step_and_rank": round(ms, 3), "kernels_ms": k,
+        total_q = B * WT
+        rec = {"mode": mode, "n_gpus": WT, "layout": f"{W}x{WT // W} (row shards x query groups)",
+               "ms_per_step_and_rank": round(ms, 3), "kernels_ms": k,
                "queries_total": total_q, "compute_only_geo_embeddings_per_s": round(total_q / ms * 1e3),
                "compute_only_speedup_vs_1": round((total_q / ms) / (10000 / base.get(mode, ms)), 3),
                "chunks": n_chunks, "last_pass2_grid": [qt, ns]}
         print(json.dumps(rec) if as_json else
-              f"{mode:6s} N={W}: {ms:7.3f} ms per step and rank  kernels {k}  grid {qt} x {ns}  "
+              f"{mode:6s} N={WT} layout {W}x{WT // W}: {ms:7.3f} ms per step and rank  kernels {k}  grid {qt} x {ns}  "
               f"compute-only speed-up x{rec['compute_only_speedup_vs_1']}", flush=True)
         del eng
