@@ -85,17 +85,21 @@ struct EncArgs {
     const double* bias[ENC_MAX_LAYERS];
 };
 
-// LDS address (in doubles) of activation element (query q in 0..31, k) in fragment order:
-// fragment (kstep, qtile) = 64 doubles = the A operand of one MFMA: lane (kq = k&3, ql = q&15).
+// LDS address (in doubles) of activation element (query q in 0..16 QT - 1, k) in fragment order:
+// fragment (kstep, qtile) = 64 doubles = the A operand of one MFMA: lane (kq = k&3, ql = q&15);
+// QT = 16-query tiles of the workgroup (a 16-query workgroup packs its one tile densely: that is
+// what lets hidden widths up to 1024 - 16 x 1024 float64 = 128 KB - fit the LDS).
 // The XOR term spreads the 16 lanes of an accumulator write-back (16 consecutive k, same q)
 // over 16 bank pairs; a fragment read (fixed k, ql = 0..15) stays a contiguous permutation.
+template <int QT>
 __device__ __forceinline__ int act_addr(int q, int k) {
     const int kstep = k >> 2, kq = k & 3;
-    return ((kstep * 2 + (q >> 4)) << 6) + (kq << 4) + ((q & 15) ^ ((kq << 2) | (kstep & 3)));
+    return ((kstep * QT + (q >> 4)) << 6) + (kq << 4) + ((q & 15) ^ ((kq << 2) | (kstep & 3)));
 }
+template <int QT>
 __device__ __forceinline__ int frag_addr(int kstep, int qt, int lane) {
     const int kq = lane >> 4;
-    return ((kstep * 2 + qt) << 6) + (kq << 4) + ((lane & 15) ^ ((kq << 2) | (kstep & 3)));
+    return ((kstep * QT + qt) << 6) + (kq << 4) + ((lane & 15) ^ ((kq << 2) | (kstep & 3)));
 }
 
 // acc[qt][i] += A(lds, 2*kpairs k-steps) x Wp rows owned by this wave (NTW n-tiles).
@@ -134,10 +138,10 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
         for (int d = 0; d < ENC_PF; ++d) {
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
-            const double a00 = lds[frag_addr(ks, 0, lane)];
-            const double a01 = QT > 1 ? lds[frag_addr(ks, 1, lane)] : 0.0;
-            const double a10 = lds[frag_addr(ks + 1, 0, lane)];
-            const double a11 = QT > 1 ? lds[frag_addr(ks + 1, 1, lane)] : 0.0;
+            const double a00 = lds[frag_addr<QT>(ks, 0, lane)];
+            const double a01 = QT > 1 ? lds[frag_addr<QT>(ks, 1, lane)] : 0.0;
+            const double a10 = lds[frag_addr<QT>(ks + 1, 0, lane)];
+            const double a11 = QT > 1 ? lds[frag_addr<QT>(ks + 1, 1, lane)] : 0.0;
             f64x2 b[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) b[i] = bq[d][i];
@@ -163,10 +167,10 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
         if (kp0 + d < kpairs) {
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
-            const double a00 = lds[frag_addr(ks, 0, lane)];
-            const double a01 = QT > 1 ? lds[frag_addr(ks, 1, lane)] : 0.0;
-            const double a10 = lds[frag_addr(ks + 1, 0, lane)];
-            const double a11 = QT > 1 ? lds[frag_addr(ks + 1, 1, lane)] : 0.0;
+            const double a00 = lds[frag_addr<QT>(ks, 0, lane)];
+            const double a01 = QT > 1 ? lds[frag_addr<QT>(ks, 1, lane)] : 0.0;
+            const double a10 = lds[frag_addr<QT>(ks + 1, 0, lane)];
+            const double a11 = QT > 1 ? lds[frag_addr<QT>(ks + 1, 1, lane)] : 0.0;
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 acc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, bq[d][i].x, acc[0][i], 0, 0, 0);
@@ -191,7 +195,7 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = qt * 16 + (lane >> 4) + 4 * r;
-                lds[act_addr(q, n)] = sin(w0 * (acc[qt][i][r] + bn));
+                lds[act_addr<QT>(q, n)] = sin(w0 * (acc[qt][i][r] + bn));
             }
     }
 }
@@ -339,16 +343,16 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                         }
                         if (d.kx) v *= pw[d.kx];
                         if (m == 0) {
-                            lds[act_addr(gq, pos_m + (l - m))] = v;
+                            lds[act_addr<QT>(gq, pos_m + (l - m))] = v;
                         } else {
-                            lds[act_addr(gq, pos_m + 2 * (l - m))] = v * cm;
-                            lds[act_addr(gq, pos_m + 2 * (l - m) + 1)] = v * sm;
+                            lds[act_addr<QT>(gq, pos_m + 2 * (l - m))] = v * cm;
+                            lds[act_addr<QT>(gq, pos_m + 2 * (l - m) + 1)] = v * sm;
                         }
                     }
                     pos_m += (m == 0 ? 1 : 2) * (L - m);
                 }
                 if (gsub == 0)
-                    for (int pos = pos_m; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
+                    for (int pos = pos_m; pos < end; ++pos) lds[act_addr<QT>(gq, pos)] = 0.0;
             }
 #ifdef RANGE_EXP_ENC_NOGEN
         } else if (false) {
@@ -373,14 +377,14 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                                               : a.coefA[l * L + m] * cx * q1 - a.coefB[l * L + m] * q2;
                     q2 = q1; q1 = v;
                     if (m == 0) {
-                        lds[act_addr(gq, pos++)] = v;
+                        lds[act_addr<QT>(gq, pos++)] = v;
                     } else {
-                        lds[act_addr(gq, pos++)] = v * cm;
-                        lds[act_addr(gq, pos++)] = v * sm;
+                        lds[act_addr<QT>(gq, pos++)] = v * cm;
+                        lds[act_addr<QT>(gq, pos++)] = v * sm;
                     }
                 }
             }
-            for (; pos < end; ++pos) lds[act_addr(gq, pos)] = 0.0;
+            for (; pos < end; ++pos) lds[act_addr<QT>(gq, pos)] = 0.0;
         }
         __syncthreads();
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
@@ -409,7 +413,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         // the activated second layer of this tile, written by the MODE 3 workgroups
         for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
             const int q = idx / a.H, k = idx - q * a.H;
-            lds[act_addr(q, k)] = a.h2[(q0 + q) * a.H + k];
+            lds[act_addr<QT>(q, k)] = a.h2[(q0 + q) * a.H + k];
         }
     } else if (MODE == 2 || MODE == 3) {
         // first layer of this tile: the K parts summed in a fixed order, then
@@ -419,7 +423,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
             const int q = idx / a.H, k = idx - q * a.H;
             double v = a.h1[(q0 + q) * a.H + k];
             for (int kp = 1; kp < a.n_kparts; ++kp) v += a.h1[((int64_t)kp * rows + q0 + q) * a.H + k];
-            lds[act_addr(q, k)] = sin(30.0 * (v + a.bias[0][k]));
+            lds[act_addr<QT>(q, k)] = sin(30.0 * (v + a.bias[0][k]));
         }
     }
     if (MODE == 3) {
@@ -564,8 +568,13 @@ template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
-    if (b < a.n_wg32) encoder_body<NT, NW, 2>(a, (int64_t)b * 32, smem);
-    else encoder_body<NT, NW, 1>(a, (int64_t)a.n_wg32 * 32 + (int64_t)(b - a.n_wg32) * 16, smem);
+    if constexpr (NT <= 8) {     // (wider encoders run 16-query workgroups only: 32 x H float64 would not fit the LDS)
+        if (b < a.n_wg32) {
+            encoder_body<NT, NW, 2>(a, (int64_t)b * 32, smem);
+            return;
+        }
+    }
+    encoder_body<NT, NW, 1>(a, (int64_t)a.n_wg32 * 32 + (int64_t)(b - a.n_wg32) * 16, smem);
 }
 
 }  // namespace range_hip

@@ -145,6 +145,12 @@ int set_dyn_lds(K kernel, size_t bytes) {
 // a workgroup streams - is split over S column parts per tile on S times as many workgroups
 // (encoder_l1_part_kernel), the rest follows per tile (encoder_rest_kernel).  One workgroup's
 // serial chain over all weights takes 0.28 ms whatever the batch; this pair takes about half.
+// the first layer's part kernels exist for parts of 64, 128, 256 and 512 columns
+inline bool split_width_ok(int H, int S) {
+    const int part = H / S;
+    return H % S == 0 && (part == 64 || part == 128 || part == 256 || part == 512);
+}
+
 int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) {
     const int tiles = (int)((a.B + 15) / 16);
     if (c->ws_h1.ensure((size_t)KP * tiles * 16 * a.H) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
@@ -217,6 +223,8 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         RANGE_ENC_REST(4, RANGE_ENC_WAVES)
         RANGE_ENC_REST(6, 4)
         RANGE_ENC_REST(8, RANGE_ENC_WAVES)
+        RANGE_ENC_REST(12, 16)
+        RANGE_ENC_REST(16, 16)
         default: return fail(RANGE_ERR_INVALID, "internal: hidden width %d", a.H);
     }
 #undef RANGE_ENC_REST
@@ -231,8 +239,9 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
         const int64_t tiles = (a.B + 15) / 16;
         int S, KP;
         choose_encoder_split(c->n_cu, a.n_slots, a.H, tiles, S, KP);
-        if (S * KP > 1 && c->enc_split) return launch_encoder_split(c, a, S, KP, s);
+        if (S * KP > 1 && c->enc_split && split_width_ok(a.H, S)) return launch_encoder_split(c, a, S, KP, s);
     }
+    const bool only16 = a.H > 512;       // (32 queries x H float64 of activations do not fit the LDS)
     // Workgroups take 32 queries and cost the same, one per CU at a time.  When the last round of
     // them would be less than half full, it is run with 16-query workgroups instead (about half
     // the time each): 10 000 queries = 256 x 32 + 113 x 16 instead of 313 x 32.
@@ -242,10 +251,10 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     // A tail of up to 2 048 queries after full rounds runs as the small-batch kernels (its tiles
     // spread over all CUs: ~0.16 ms for 1 808 queries) instead of a round of 16-query workgroups
     // (0.23 ms whatever its fill): 10 000 queries = 256 x 32 + a split tail of 113 tiles.
-    if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split) {
+    if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split && !only16) {
         int S, KP;
         choose_encoder_split(c->n_cu, a.n_slots, a.H, (rem + 15) / 16, S, KP);
-        if (S * KP > 1) {
+        if (S * KP > 1 && split_width_ok(a.H, S)) {
             const int64_t b_main = a.B - rem;
             EncArgs m = a;
             m.B = b_main;
@@ -262,7 +271,7 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
         }
     }
     int grid;
-    if (a.B <= (int64_t)16 * c->n_cu) {
+    if (only16 || a.B <= (int64_t)16 * c->n_cu) {
         // a batch that fits in one round either way: half-size workgroups on twice the CUs
         a.n_wg32 = 0;
         grid = (int)((a.B + 15) / 16);
@@ -292,6 +301,8 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
         RANGE_ENC_CASE(6, 4)
         RANGE_ENC_CASE(7, 4)
         RANGE_ENC_CASE(8, RANGE_ENC_WAVES)
+        RANGE_ENC_CASE(12, 16)
+        RANGE_ENC_CASE(16, 16)
         default:
             return fail(RANGE_ERR_INVALID, "unsupported hidden width %d", a.H);
     }
@@ -427,7 +438,8 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     if (!c || !d || !weights || !biases) return fail(RANGE_ERR_INVALID, "null argument");
     const int L = d->legendre_polys, H = d->hidden, NL = d->num_hidden_layers, E = d->embed_dim;
     if (L < 1 || L > 64) return fail(RANGE_ERR_INVALID, "legendre_polys %d unsupported (1..64)", L);
-    if (H < 64 || H > 512 || H % 64) return fail(RANGE_ERR_INVALID, "hidden %d unsupported (multiple of 64, <=512)", H);
+    if (!((H >= 64 && H <= 512 && H % 64 == 0) || H == 768 || H == 1024))
+        return fail(RANGE_ERR_INVALID, "hidden %d unsupported (multiples of 64 up to 512, 768, 1024)", H);
     if (NL < 1 || NL + 1 > ENC_MAX_LAYERS) return fail(RANGE_ERR_INVALID, "num_hidden_layers %d unsupported", NL);
     if (E != ENC_EMBED) return fail(RANGE_ERR_INVALID, "embed_dim %d unsupported (must be 256)", E);
     if (d->sh_mode != RANGE_SH_ANALYTIC && d->sh_mode != RANGE_SH_CLOSED_FORM)
@@ -442,7 +454,8 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     const std::vector<int>& perm = plan.perm;
     const std::vector<int32_t>& slot_base = plan.slot_base;
     const int n_slots = plan.n_slots, n_rounds = plan.n_rounds, Kp = (int)perm.size();
-    const int lds_main = ENC_QTILE * std::max(plan.max_round, H);
+    // (hidden widths beyond 512 run 16-query workgroups only, their activations packed densely)
+    const int lds_main = (H > 512 ? 16 : ENC_QTILE) * std::max(plan.max_round, H);
     const size_t lds_bytes = (size_t)(lds_main + 16 * ENC_QTILE) * sizeof(double);   // + [<= 16 waves][32] partial norms
     if (lds_bytes > 160 * 1024) return fail(RANGE_ERR_INVALID, "encoder shape needs %zu B of LDS (>160 KiB)", lds_bytes);
     std::vector<double> coefA, coefB, seedc;

@@ -271,3 +271,41 @@ def test_unnormalised_bank_is_refused_by_the_softmax():
     tv, ti = eng.topk_stream(q, 4)                                     # the top-k takes any norm
     s64 = q.cpu().numpy().astype(np.float64) @ keys.astype(np.float64).T
     assert np.array_equal(ti.cpu().numpy(), O.topk64(s64, 4)[1])
+
+
+@pytest.mark.parametrize("L,H,layers,mode,Bs", [
+    (10, 768, 2, "analytic", (5, 300, 5000)),
+    (10, 1024, 2, "closed-form", (1, 16, 700, 4500)),
+    (40, 1024, 2, "analytic", (40, 2100)),
+    (16, 1024, 3, "analytic", (33,)),
+])
+def test_encoder_wide_hidden_layers(L, H, layers, mode, Bs):
+    """`capacity` of the real checkpoint is unknown: hidden widths beyond 512 - 768
+    and 1024 - run 16-query workgroups whose activations are packed densely in LDS (16 x H float64).
+    Every batch geometry: one kernel, the small-batch split kernels, many rounds; both SH evaluations
+    (the exact recurrence against the float64 oracle; the reference's polynomials against their CPU
+    evaluation through the same Siren)."""
+    w, ws, bs = _weights(L, H, layers, 12)
+    smode = _native.SH_ANALYTIC if mode == "analytic" else _native.SH_CLOSED_FORM
+    exact = _native.HipEngine("cuda:0")
+    exact.set_encoder(L, H, layers, 256, smode, ws, bs)
+    engines = [(exact, None)]
+    if mode == "analytic":
+        tab = sh_table.generate_table(L)
+        faithful = _native.HipEngine("cuda:0")
+        faithful.set_encoder(L, H, layers, 256, smode, ws, bs, sh_table=tab)
+        engines.append((faithful, tab))
+    for B in Bs:
+        q = synth.make_queries(B, seed=B, lat_max=40.0)
+        x = torch.from_numpy(q).cuda()
+        for eng, tab in engines:
+            e64, e32, xq = eng.encode(x)
+            ref = O.encode(q, w, L, mode) if tab is None else O.encode(q, w, L, features=tab.evaluate(q))
+            np.testing.assert_allclose(e64.cpu().numpy(), ref, rtol=0, atol=4e-12 if tab is None else 2e-7)
+            np.testing.assert_array_equal(e32.cpu().numpy(), e64.cpu().numpy().astype(np.float32))
+            raw = eng.encode_raw(x).cpu().numpy()
+            np.testing.assert_allclose(raw / np.linalg.norm(raw, axis=1, keepdims=True), e64.cpu().numpy(), rtol=0, atol=1e-13)
+    with pytest.raises(_native.RangeNativeError, match="unsupported"):
+        bad = _native.HipEngine("cuda:0")
+        wb, wsb, bsb = _weights(10, 640, 2, 1)
+        bad.set_encoder(10, 640, 2, 256, _native.SH_ANALYTIC, wsb, bsb)

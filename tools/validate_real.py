@@ -52,9 +52,9 @@ def main():
         print(f"  layer {i}: weight {tuple(w.shape)} {w.dtype}, |w| max {np.abs(w).max():.3e}, bias {tuple(b.shape)}")
     if not 1 <= L <= 64:
         fail(f"legendre_polys={L}: the encoder kernel covers 1..64 (range_amd/csrc/range_hip.hip: range_set_encoder)")
-    if H % 64 or not 64 <= H <= 512:
-        fail(f"capacity H={H}: the encoder kernel covers multiples of 64 up to 512 (its hidden activations of a 32-query "
-             "workgroup live in LDS: 32 x H float64; range_amd/csrc/range_hip.hip: range_set_encoder)")
+    if not ((H % 64 == 0 and 64 <= H <= 512) or H in (768, 1024)):
+        fail(f"capacity H={H}: the encoder kernel covers multiples of 64 up to 512, 768 and 1024 (the hidden activations "
+             "of a 16-query workgroup live in LDS: 16 x H float64 <= 128 KB; range_amd/csrc/range_hip.hip: range_set_encoder)")
     if E != 256:
         fail(f"embed_dim={E}: the bank keys are 256 wide (range/range.py:85-86) and so are the kernels")
     if not 1 <= NL <= 7:
