@@ -20,6 +20,7 @@
 #include "attend_kernels.h"
 #include "topk_stream.h"
 #include "attend_bf16x3.h"
+#include "attend_small.h"
 #include "encoder_kernel.h"
 
 using namespace range_hip;
@@ -89,6 +90,8 @@ struct range_ctx {
     bool topks_fused = true;                 // RANGE_TOPKS_FUSED=0: the merge as a second launch at every batch size (A/B)
     DevBuf<uint32_t> ws_topk_sync;           // TOPKS_SYNC_WORDS: arrival counters, done, sticky error, key-norm scratch
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
+    bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 16 queries take the two-pass kernels too (A/B)
+    DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
@@ -326,8 +329,8 @@ int build_vplanes(range_ctx* c) {
     return RANGE_OK;
 }
 
-int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* xq, int64_t B,
-                   float tau_sem, float tau_geo, bool pass1, int p1_max_splits = 128) {
+// preconditions of every kernel that forms softmax weights with the constant shift m = tau * log2(e)
+int check_softmax_args(range_ctx* c, int64_t B, float tau_sem, float tau_geo) {
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
     if (!c->has_values)
         return fail(RANGE_ERR_STATE, "keys-only bank (range_set_keys): only range_topk_stream runs on it");
@@ -342,6 +345,13 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     if (tau_geo > 0.f && c->xyz_norm_max > 1.001f)
         return fail(RANGE_ERR_INVALID, "bank locations are not unit vectors (largest row norm %.4f): the geographic "
                     "softmax needs them as range/utils/utils.py:11-16 computes them", (double)c->xyz_norm_max);
+    return RANGE_OK;
+}
+
+int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* xq, int64_t B,
+                   float tau_sem, float tau_geo, bool pass1, int p1_max_splits = 128) {
+    int rc0 = check_softmax_args(c, B, tau_sem, tau_geo);
+    if (rc0) return rc0;
     // the softmax statistics use the constant shift m = tau * log2(e) (scan_stats_kernel): the
     // smallest term 2^(-2m) must stay a normal float32
     if (tau_sem > RANGE_MAX_TAU || tau_geo > RANGE_MAX_TAU)
@@ -420,6 +430,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
     if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_SMALL_FORWARD")) c->small_forward = e[0] != '0';
     *out = c;
     return RANGE_OK;
 }
@@ -1221,6 +1232,68 @@ int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const d
     return RANGE_OK;
 }
 
+// Up to 16 queries: the whole retrieval in ONE pass over the bank (attend_small.h) - every CU
+// streams its share of keys, locations and values once and accumulates the un-normalised products
+// of both heads; small_finalize_kernel sums the workgroups' partials, normalises, blends and packs.
+// e-hat / xq of the B queries are in the context's workspace (range_encode ran on `stream`).
+static int forward_small(range_ctx* c, int64_t B, float tau_sem, float tau_geo, float beta, double* out,
+                         hipStream_t s) {
+    int rc = check_softmax_args(c, B, tau_sem, tau_geo);
+    if (rc) return rc;
+    if (tau_sem > RANGE_MAX_TAU || tau_geo > RANGE_MAX_TAU)
+        return fail(RANGE_ERR_INVALID, "temperatures above %g are not supported", (double)RANGE_MAX_TAU);
+    const double LOG2E = 1.4426950408889634;
+    const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
+    const int n_wg = std::max(1, std::min(c->n_cu, n_blocks));
+    HIP_TRY(c->ws_small_o.ensure((size_t)n_wg * 2 * 16 * VAL_DIM));
+    HIP_TRY(c->ws_small_z.ensure((size_t)n_wg * 16 * 2));
+    SmallArgs a{};
+    a.keys = c->d_keys.p;
+    a.xyz4 = c->d_xyz4.p;
+    a.values = c->d_values.p;
+    a.ehat = c->ws_ehat32.p;
+    a.xq = c->ws_xq.p;
+    a.osum = c->ws_small_o.p;
+    a.zsum = c->ws_small_z.p;
+    a.B = B;
+    a.n_valid = c->n_rows;
+    a.n_blocks = n_blocks;
+    a.k_sem = (float)(tau_sem * LOG2E);
+    a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
+    const bool geo = tau_geo > 0.f;
+    {
+        ProfScope ps(c, RANGE_PROF_ATTEND, s);
+        if (geo) {
+            rc = set_dyn_lds(attend_small_kernel<true>, AS_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_small_kernel<true>, dim3((unsigned)n_wg), dim3(256), AS_LDS_BYTES, s, a);
+        } else {
+            rc = set_dyn_lds(attend_small_kernel<false>, AS_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(attend_small_kernel<false>, dim3((unsigned)n_wg), dim3(256), AS_LDS_BYTES, s, a);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(small_finalize_kernel, dim3((unsigned)B, 8), dim3(256), 0, s, c->ws_small_o.p, c->ws_small_z.p,
+                       n_wg, geo ? 1 : 0, geo ? beta : 1.0f, c->ws_ehat64.p, out);
+    HIP_TRY(hipGetLastError());
+    c->last_qtiles = 1;
+    c->last_splits = n_wg;
+    return RANGE_OK;
+}
+
+static int encode_to_workspace(range_ctx* c, const double* lonlat, int64_t B, range_stream_t stream) {
+    {
+        DeviceGuard g(c->device);
+        if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+        HIP_TRY(c->ws_ehat64.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
+        HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
+        HIP_TRY(c->ws_stats.ensure((size_t)B * 4));
+    }
+    return range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
+}
+
 // encode -> pass 1 (keeping its logits) -> pass 2 into the context's split slabs; the caller
 // finalizes (sums the slabs, packs with e-hat).  n_splits_out = number of slabs written.
 static int forward_to_slabs(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
@@ -1252,6 +1325,16 @@ static int forward_to_slabs(range_ctx* c, const double* lonlat, int64_t B, int32
 int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
                   double* out, range_stream_t stream) {
     if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
+    if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
+        return fail(RANGE_ERR_INVALID, "unknown model %d", model);
+    if (B > 0 && B <= 16 && c->small_forward) {
+        // a handful of queries: one pass over the bank (attend_small.h)
+        int rc = encode_to_workspace(c, lonlat, B, stream);
+        if (rc) return rc;
+        DeviceGuard g(c->device);
+        return forward_small(c, B, model == RANGE_MODEL_RANGE ? 15.0f : 12.0f, model == RANGE_MODEL_RANGE ? 0.0f : 40.0f,
+                             beta, out, (hipStream_t)stream);
+    }
     // single GPU: the finalize kernel sums the split slabs itself (same fixed order as
     // reduce_parts_kernel, so the result is bit-identical to attend + finalize)
     int n_splits = 0;
@@ -1302,6 +1385,15 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     const float bt = model == RANGE_MODEL_RANGE ? 1.0f : beta;
     int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
     if (rc) return rc;
+    if (B <= 16 && c->small_forward) {
+        // a handful of queries: one pass over the bank, one small copy
+        rc = forward_small(c, B, tau_sem, tau_geo, bt, c->ws_out64.p, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_stage, c->ws_out64.p, (size_t)B * row_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(out_host, c->h_stage, (size_t)B * row_bytes);
+        return RANGE_OK;
+    }
     rc = range_scan_stats(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo, c->ws_stats.p, 0,
                           nullptr, nullptr, /*keep_logits=*/1, stream);
     if (rc) return rc;

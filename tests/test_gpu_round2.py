@@ -309,3 +309,43 @@ def test_encoder_wide_hidden_layers(L, H, layers, mode, Bs):
         bad = _native.HipEngine("cuda:0")
         wb, wsb, bsb = _weights(10, 640, 2, 1)
         bad.set_encoder(10, 640, 2, 256, _native.SH_ANALYTIC, wsb, bsb)
+
+
+@pytest.mark.parametrize("N", [9, 1000, 20011])
+def test_small_batches_take_one_pass_over_the_bank(N, monkeypatch):
+    """Up to 16 queries run attend_small_kernel (every CU streams its share of keys, locations and
+    values ONCE and accumulates the un-normalised products of both heads) + small_finalize_kernel:
+    against the float64 oracle and the reference's float32 op order, RANGE and RANGE+, several beta,
+    banks that do not fill a 16-row block or have fewer blocks than CUs; the two-pass kernels
+    (RANGE_SMALL_FORWARD=0) agree to float32 rounding; 17 queries take the two-pass route."""
+    L, H = 10, 64
+    w, ws, bs = _weights(L, H, 2, 5)
+    locs, vals, keys = synth.make_bank(N, 3)
+    vals = vals.copy()
+    vals[:, 0] = 1.0                       # a constant column: reproduced iff the weights sum to one
+    bank = prepare_bank(locs, vals, keys)
+    obank = O.prep_bank(locs, vals, keys)
+    eng = _native.HipEngine("cuda:0")
+    monkeypatch.setenv("RANGE_SMALL_FORWARD", "0")
+    two = _native.HipEngine("cuda:0")
+    monkeypatch.delenv("RANGE_SMALL_FORWARD")
+    for e in (eng, two):
+        e.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+        e.set_bank(bank.keys, bank.values, bank.xyz)
+    for B in (1, 5, 16, 17):
+        q = synth.make_queries(B, seed=N + B, lat_max=80.0)
+        x = torch.from_numpy(q).cuda()
+        for model, name, beta in ((_native.MODEL_RANGE_PLUS, "RANGE+", 0.5), (_native.MODEL_RANGE_PLUS, "RANGE+", 0.0),
+                                  (_native.MODEL_RANGE_PLUS, "RANGE+", 1.0), (_native.MODEL_RANGE, "RANGE", 1.0)):
+            out = eng.forward(x, model, beta).cpu().numpy()
+            qt, ns = eng.last_geometry()
+            assert (qt == 1 and ns == min(256, (N + 15) // 16)) == (B <= 16)      # which route ran
+            ref64 = O.retrieve64(out[:, 1024:], q, obank, name, beta)
+            np.testing.assert_allclose(out[:, :1024], ref64, rtol=0, atol=2e-5)
+            np.testing.assert_allclose(out, O.retrieve(out[:, 1024:], q, obank, name, beta), rtol=0, atol=1e-4)
+            assert np.abs(out[:, 0] - 1.0).max() < 2e-6
+            np.testing.assert_allclose(out[:, 1024:], O.encode(q, w, L), rtol=0, atol=2e-12)
+            other = two.forward(x, model, beta).cpu().numpy()
+            np.testing.assert_allclose(out, other, rtol=0, atol=3e-6)
+            host = eng.forward_host(x, model, beta)                            # the numpy contract, same route
+            assert np.array_equal(host, out)

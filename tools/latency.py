@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Forward latency of RANGE+ for small batches on the bench workload (GPU only): device-resident
-queries in, device-resident embeddings out, mean of 50 calls after warm-up."""
+queries in, device-resident embeddings out, mean of 50 calls after warm-up, and the kernels' own
+times (HIP events per kernel).  Up to 16 queries run the one-pass kernel (attend_small.h;
+RANGE_SMALL_FORWARD=0 sends them through the two-pass kernels for comparison)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from range_amd import _native, synth
+from range_amd import _native, synth, sh_table
 from range_amd.bank import prepare_bank
 
 dev = torch.device("cuda:0")
@@ -12,9 +14,9 @@ bank = prepare_bank(*synth.make_bank(100000, 2024))
 w = synth.make_encoder_weights(40, 512, 256, 2, 1234)
 eng = _native.HipEngine(dev)
 eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
-                [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
+                [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]], sh_table=sh_table.generate_table(40))
 eng.set_bank(bank.keys, bank.values, bank.xyz)
-for B in (1, 16, 64, 256, 1024, 4096):
+for B in (1, 8, 16, 17, 32, 64, 256, 1024, 4096):
     x = torch.from_numpy(synth.make_queries(B, seed=B)).to(dev)
     out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
     for _ in range(5):
@@ -26,4 +28,11 @@ for B in (1, 16, 64, 256, 1024, 4096):
         eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5, out=out)
     b.record(); b.synchronize()
     us = a.elapsed_time(b) / 50 * 1e3
-    print(f"B={B:5d}: {us:9.1f} us per forward  ({B / us * 1e6:10.0f} geo-embeddings/s)")
+    eng.profile_enable(True)
+    for _ in range(20):
+        eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5, out=out)
+    torch.cuda.synchronize()
+    k = {nm: eng.profile_read(i) for i, nm in enumerate(["encoder", "pass1", "pass2_or_onepass"])}
+    eng.profile_enable(False)
+    ks = ", ".join(f"{nm} {ms / 20 * 1e3:.1f} us/{n // 20}" for nm, (ms, n) in k.items() if n)
+    print(f"B={B:5d}: {us:9.1f} us per forward  ({B / us * 1e6:10.0f} geo-embeddings/s); event pairs per forward: {ks}", flush=True)
