@@ -81,6 +81,9 @@ struct EncArgs {
     int32_t n_parts2;
     int32_t part2_cols;
     int32_t rest_from;
+    // ... and, for a few tiles, the LAST layer over 4 parts of 64 outputs per tile (MODE 4: raw
+    // outputs + bias to e3); encoder_norm_kernel then normalises and writes the results
+    double* e3;                 // (ceil(B/16)*16, 256) f64
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -224,7 +227,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                                              int kpart = 0) {
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
-    static_assert(NTW * NW == 4 * NT && (MODE == 1 || MODE == 3 || EW * NW == 16), "n-tiles must divide among the waves");
+    static_assert(MODE == 4 || (NTW * NW == 4 * NT && (MODE == 1 || MODE == 3 || EW * NW == 16)), "n-tiles must divide among the waves");
     double* lds = reinterpret_cast<double*>(smem);
     double* red = lds + a.lds_main_doubles;      // [NW waves][32 queries]
 
@@ -409,7 +412,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         return;
     }
     const int l0 = MODE == 2 ? a.rest_from : 0;   // first layer whose activation is already in LDS
-    if (MODE == 2 && l0 == 1) {
+    if ((MODE == 2 && l0 == 1) || MODE == 4) {
         // the activated second layer of this tile, written by the MODE 3 workgroups
         for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
             const int q = idx / a.H, k = idx - q * a.H;
@@ -425,6 +428,23 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
             for (int kp = 1; kp < a.n_kparts; ++kp) v += a.h1[((int64_t)kp * rows + q0 + q) * a.H + k];
             lds[act_addr<QT>(q, k)] = sin(30.0 * (v + a.bias[0][k]));
         }
+    }
+    if (MODE == 4) {
+        // 64 outputs of the last layer (Identity activation, location_encoder.py:95-96, 112): one n-tile
+        // per wave (4 waves), raw value + bias to e3; the norm follows in encoder_norm_kernel
+        __syncthreads();
+        const int kpH4 = a.H >> 3;
+        f64x4 ae4[1][1] = {{f64x4{0, 0, 0, 0}}};
+        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) + ((int64_t)(part * 4 + wave) * kpH4) * 64 + lane;
+        gemm_kpairs<1, 1>(lds, wp, kpH4, kpH4, (int)((blockIdx.x * 7u) % (unsigned)kpH4), lane, ae4);
+        const int n = (part * 4 + wave) * 16 + (lane & 15);
+        const double bn = a.bias[a.n_layers][n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t q = q0 + (lane >> 4) + 4 * r;          // (rows past B are scratch rows of e3)
+            a.e3[q * ENC_EMBED + n] = ae4[0][0][r] + bn;
+        }
+        return;
     }
     if (MODE == 3) {
         // the part's columns of the second layer: h2 = sin(acc + b) (location_encoder.py:147-150, w0 = 1)
@@ -556,6 +576,43 @@ __global__ __launch_bounds__(NTP * 256, 1) void encoder_l2_part_kernel(EncArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / a.n_parts2, part = blockIdx.x - tile * a.n_parts2;
     encoder_body<NTP, 4 * NTP, 1, 3>(a, (int64_t)tile * 16, smem, part);
+}
+
+// last layer per (16-query tile, part of 64 outputs): 4 waves, one n-tile each (NT = H / 64 only
+// sizes the body's unused hidden-layer registers: 4 keeps them minimal)
+__global__ __launch_bounds__(256, 1) void encoder_l3_part_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x >> 2, part = blockIdx.x & 3;
+    encoder_body<4, 4, 1, 4>(a, (int64_t)tile * 16, smem, part);
+}
+
+// e = e3 / |e3| (range.py:212), its float32 copy, the raw output if asked for, and the query's unit
+// vector (float64 trig, then .float(): range.py:225-231, utils.py:11-16).  One wave per query.
+__global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.B) return;
+    double v[4], ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a.e3[q * ENC_EMBED + 64 * i + lane]; ss += v[i] * v[i]; }
+    // (the summation order of the one-kernel encoder: 16 columns of an n-tile across lanes, n-tiles in order)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) ss += __shfl_xor(ss, off);
+    const double nrm = sqrt(ss);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = 64 * i + lane;
+        const double e = v[i] / nrm;
+        if (a.eraw64) a.eraw64[q * ENC_EMBED + n] = v[i];
+        a.ehat64[q * ENC_EMBED + n] = e;
+        a.ehat32[q * ENC_EMBED + n] = (float)e;
+    }
+    if (lane == 0) {
+        const double lon = a.lonlat[2 * q] * 3.14159265358979323846 / 180.0;
+        const double lat = a.lonlat[2 * q + 1] * 3.14159265358979323846 / 180.0;
+        const double cl = cos(lat);
+        *reinterpret_cast<float4*>(a.xq + q * 4) = make_float4((float)(cl * cos(lon)), (float)(cl * sin(lon)), (float)sin(lat), 0.f);
+    }
 }
 
 template <int NT, int NW>

@@ -79,6 +79,7 @@ struct range_ctx {
     bool warned_no_keep = false;
     bool enc_split = true;    // RANGE_ENC_SPLIT=0: small batches use the one-kernel encoder too
     bool enc_split2 = true;   // RANGE_ENC_SPLIT2=0: ... without the second layer's own split
+    bool enc_split3 = false;  // RANGE_ENC_SPLIT3=1: the last layer split too for up to 8 tiles (measured slower: see launch_encoder_split)
     bool enc_tail_split = true;   // RANGE_ENC_TAIL=0: the last partial round of a large batch as 16-query workgroups
     DevBuf<int32_t> ws_cand_idx;
     DevBuf<unsigned long long> ws_cand_keys;
@@ -95,7 +96,7 @@ struct range_ctx {
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
-    DevBuf<double> ws_ehat64, ws_h1, ws_h2;
+    DevBuf<double> ws_ehat64, ws_h1, ws_h2, ws_e3;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
@@ -188,8 +189,16 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     // equal, 625 queries 127 -> 118, 1 250 queries 145 -> 135, 2 048 queries 170 -> 162 us: from 32
     // tiles on.
     a.rest_from = 0;
+    // A FEW tiles (up to 8: the latency regime - a handful of queries): one workgroup's chain over the
+    // second and the last layer is 12.6 MFLOP of float64 MFMA on ONE CU, 70-90 us whatever the batch.
+    // RANGE_ENC_SPLIT3=1 splits both layers too (second: column parts; last: 4 parts of 64 outputs) with
+    // a one-wave-per-query kernel to normalise - four short launches instead of two.  MEASURED SLOWER:
+    // 133 us against 111 us for 16 queries (round 3; round 2 saw the same with three launches): every
+    // dependent launch costs ~10-20 us (dispatch, then 4-6 us before a kernel's first memory access
+    // returns), more than the split saves.  Off by default; what would help is ONE persistent launch.
+    const bool few = tiles <= 8 && a.n_layers == 2 && c->enc_split3 && c->enc_split2;
     int S2 = 1;
-    for (int s2 = 2; s2 <= 8 && tiles >= 32 && tiles * s2 <= c->n_cu && a.n_layers >= 2; s2 *= 2) {
+    for (int s2 = 2; s2 <= 8 && (tiles >= 32 || few) && tiles * s2 <= c->n_cu && a.n_layers >= 2; s2 *= 2) {
         const int part = a.H / s2;
         if (a.H % s2 == 0 && (part == 64 || part == 128 || part == 256)) S2 = s2;
     }
@@ -213,6 +222,17 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         }
 #undef RANGE_ENC_PART2
         HIP_TRY(hipGetLastError());
+        if (few) {
+            if (c->ws_e3.ensure((size_t)tiles * 16 * ENC_EMBED) != hipSuccess) return fail(RANGE_ERR_NOMEM, "out of device memory");
+            a.e3 = c->ws_e3.p;
+            rc = set_dyn_lds(encoder_l3_part_kernel, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(encoder_l3_part_kernel, dim3(tiles * 4), dim3(256), lds, s, a);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(encoder_norm_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, s, a);
+            HIP_TRY(hipGetLastError());
+            return RANGE_OK;
+        }
     }
 #define RANGE_ENC_REST(NT, NW)                                                                 \
     case NT:                                                                                   \
@@ -425,6 +445,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_HOST_TIMING")) c->host_timing = e[0] == '1';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT")) c->enc_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_SPLIT3")) c->enc_split3 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_TAIL")) c->enc_tail_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
