@@ -84,9 +84,25 @@ struct EncArgs {
     // ... and, for a few tiles, the LAST layer over 4 parts of 64 outputs per tile (MODE 4: raw
     // outputs + bias to e3); encoder_norm_kernel then normalises and writes the results
     double* e3;                 // (ceil(B/16)*16, 256) f64
+    double* h1a;                // encoder_tile_kernel: the ACTIVATED first layer of the tile (16, H) f64, or null
+    // encoder_tile_kernel (one 16-query tile, one launch): 4 arrival counters, 64 words apart; zero
+    // when the context is created, left zero by every launch
+    uint32_t* sync;
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
+
+// h1 / h2 / e3 travel between workgroups: inside ONE launch (encoder_tile_kernel) that needs
+// agent-scope accesses - written through (sc1), read past the L1 (guide: Guideline 16, the
+// "every load sc1" form); between launches they are ordinary global memory either way.
+__device__ __forceinline__ void st_xwg(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_xwg(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(
+        reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 // LDS address (in doubles) of activation element (query q in 0..16 QT - 1, k) in fragment order:
 // fragment (kstep, qtile) = 64 doubles = the A operand of one MFMA: lane (kq = k&3, ql = q&15);
@@ -112,14 +128,18 @@ __device__ __forceinline__ int frag_addr(int kstep, int qt, int lane) {
 // wp points at this wave's first n-tile, pair 0, lane element; n-tile stride = kp_stride*64.
 // The fragments come straight from L2 / Infinity Cache (each wave owns its n-tiles, nothing to
 // share through LDS): one pair is 32 f64 MFMAs = 2048 cycles, less than that latency under load,
-// so the loads run ENC_PF pairs ahead in a statically indexed register ring.
+// so the loads run PF pairs ahead in a statically indexed register ring: 3 where a wave owns many
+// n-tiles (the large-batch kernel: 16 bytes x n-tiles x PF registers), 12 in the small-batch
+// kernels, whose waves own one or two n-tiles and walk ALL k-pairs of a layer alone - there the
+// chain is bound by the latency of this stream (64 pairs at 3 in flight: ~35 us per layer; round 3).
 constexpr int ENC_PF = 3;
+constexpr int ENC_PF_SMALL = 3;     // (12 was measured: 111 -> 124 us for 16 queries - not the stream's latency then)
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // kp_rot rotates the order in which the pairs are visited (pair index = (i + kp_rot) mod kpairs):
 // every workgroup streams the SAME weights, and without a per-workgroup rotation they all ask the
 // same L2 lines at the same moment.
-template <int NTW, int QT>
+template <int NTW, int QT, int PF = ENC_PF>
 __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, int kpairs,
                                             int64_t kp_stride, int kp_rot, int lane,
                                             f64x4 (&acc)[QT][NTW]) {
@@ -128,17 +148,17 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
         return i >= kpairs ? i - kpairs : i;
     };
     const int ks_base = 0;
-    f64x2 bq[ENC_PF][NTW];
+    f64x2 bq[PF][NTW];
 #pragma unroll
-    for (int d = 0; d < ENC_PF; ++d) {
+    for (int d = 0; d < PF; ++d) {
         const int kp = rot(d < kpairs ? d : kpairs - 1);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) bq[d][i] = wp[((int64_t)i * kp_stride + kp) * 64];
     }
     int kp0 = 0;
-    for (; kp0 + ENC_PF <= kpairs; kp0 += ENC_PF) {
+    for (; kp0 + PF <= kpairs; kp0 += PF) {
 #pragma unroll
-        for (int d = 0; d < ENC_PF; ++d) {
+        for (int d = 0; d < PF; ++d) {
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
             const double a00 = lds[frag_addr<QT>(ks, 0, lane)];
@@ -148,8 +168,8 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
             f64x2 b[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) b[i] = bq[d][i];
-            // refill this ring slot with pair kp + ENC_PF (clamped: the tail re-reads the last)
-            const int kn = rot(kp0 + d + ENC_PF < kpairs ? kp0 + d + ENC_PF : kpairs - 1);
+            // refill this ring slot with pair kp + PF (clamped: the tail re-reads the last)
+            const int kn = rot(kp0 + d + PF < kpairs ? kp0 + d + PF : kpairs - 1);
 #pragma unroll
             for (int i = 0; i < NTW; ++i) bq[d][i] = wp[((int64_t)i * kp_stride + kn) * 64];
 #pragma unroll
@@ -164,9 +184,9 @@ __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, 
             }
         }
     }
-    // remainder (< ENC_PF pairs): their fragments are already in the ring, in order
+    // remainder (< PF pairs): their fragments are already in the ring, in order
 #pragma unroll
-    for (int d = 0; d < ENC_PF - 1; ++d) {
+    for (int d = 0; d < PF - 1; ++d) {
         if (kp0 + d < kpairs) {
             const int kp = rot(kp0 + d);
             const int ks = ks_base + 2 * kp;
@@ -203,6 +223,12 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
     }
 }
 
+#ifdef RANGE_EXP_ENC_STAMPS   // tuning only: phase stamps of workgroup 0 / thread 0 behind e3's 16 rows (100 MHz counter)
+#define ENC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.e3) reinterpret_cast<unsigned long long*>(a.e3 + 16 * ENC_EMBED)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ENC_STAMP(i) do { } while (0)
+#endif
+
 // NT = H / 64.  NW waves per workgroup (4 or 16) share the H/16 n-tiles of 16 hidden columns:
 // NTW = 4*NT/NW per wave (and 16/NW of the 16 output n-tiles).  Sixteen waves (four per SIMD)
 // are what the float64 MFMA pipe wants (tools/micro/mfma_f64_peak.hip: 36 TFLOP/s with 1-2 waves
@@ -227,6 +253,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                                              int kpart = 0) {
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
+    constexpr int PF = (MODE != 0 && NTW <= 2) ? ENC_PF_SMALL : ENC_PF;   // depth of the weight stream's register ring
     static_assert(MODE == 4 || (NTW * NW == 4 * NT && (MODE == 1 || MODE == 3 || EW * NW == 16)), "n-tiles must divide among the waves");
     double* lds = reinterpret_cast<double*>(smem);
     double* red = lds + a.lds_main_doubles;      // [NW waves][32 queries]
@@ -393,7 +420,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[0]) +
                           ((int64_t)((MODE == 1 ? part * (a.part_cols >> 4) : 0) + wave * NTW) * a.kp0_total + (kp0 >> 3)) * 64 + lane;
         if (NWT == NW || wave < NW)
-            gemm_kpairs<NTW, QT>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
+            gemm_kpairs<NTW, QT, PF>(lds, wp, (kp1 - kp0) >> 3, a.kp0_total, (int)((blockIdx.x * 7u) % (unsigned)((kp1 - kp0) >> 3)), lane, acc);
     }
 
     if (MODE == 1) {
@@ -406,7 +433,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t q = q0 + (lane >> 4) + 4 * r;      // (rows past B are scratch rows of h1)
-                a.h1[((int64_t)kpart * rows + q) * a.H + n] = acc[0][i][r];
+                st_xwg(a.h1 + ((int64_t)kpart * rows + q) * a.H + n, acc[0][i][r]);
             }
         }
         return;
@@ -414,18 +441,24 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     const int l0 = MODE == 2 ? a.rest_from : 0;   // first layer whose activation is already in LDS
     if ((MODE == 2 && l0 == 1) || MODE == 4) {
         // the activated second layer of this tile, written by the MODE 3 workgroups
-        for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
+        for (int idx = tid; idx < QT * 16 * a.H; idx += blockDim.x) {
             const int q = idx / a.H, k = idx - q * a.H;
-            lds[act_addr<QT>(q, k)] = a.h2[(q0 + q) * a.H + k];
+            lds[act_addr<QT>(q, k)] = ld_xwg(a.h2 + (q0 + q) * a.H + k);
+        }
+    } else if (MODE == 3 && a.h1a) {
+        // (encoder_tile_kernel: the first layer was summed and activated by an earlier phase)
+        for (int idx = tid; idx < QT * 16 * a.H; idx += blockDim.x) {
+            const int q = idx / a.H, k = idx - q * a.H;
+            lds[act_addr<QT>(q, k)] = ld_xwg(a.h1a + (q0 + q) * a.H + k);
         }
     } else if (MODE == 2 || MODE == 3) {
         // first layer of this tile: the K parts summed in a fixed order, then
         // h1 = sin(30 * (sum + b)) (location_encoder.py:119, 147-150)
         const int64_t rows = ((a.B + 15) / 16) * 16;
-        for (int idx = tid; idx < QT * 16 * a.H; idx += NW * 64) {
+        for (int idx = tid; idx < QT * 16 * a.H; idx += blockDim.x) {
             const int q = idx / a.H, k = idx - q * a.H;
-            double v = a.h1[(q0 + q) * a.H + k];
-            for (int kp = 1; kp < a.n_kparts; ++kp) v += a.h1[((int64_t)kp * rows + q0 + q) * a.H + k];
+            double v = ld_xwg(a.h1 + (q0 + q) * a.H + k);
+            for (int kp = 1; kp < a.n_kparts; ++kp) v += ld_xwg(a.h1 + ((int64_t)kp * rows + q0 + q) * a.H + k);
             lds[act_addr<QT>(q, k)] = sin(30.0 * (v + a.bias[0][k]));
         }
     }
@@ -433,26 +466,30 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         // 64 outputs of the last layer (Identity activation, location_encoder.py:95-96, 112): one n-tile
         // per wave (4 waves), raw value + bias to e3; the norm follows in encoder_norm_kernel
         __syncthreads();
+        if (wave >= 4) return;                               // (encoder_tile_kernel: 16 waves fill the LDS, 4 compute)
         const int kpH4 = a.H >> 3;
         f64x4 ae4[1][1] = {{f64x4{0, 0, 0, 0}}};
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) + ((int64_t)(part * 4 + wave) * kpH4) * 64 + lane;
-        gemm_kpairs<1, 1>(lds, wp, kpH4, kpH4, (int)((blockIdx.x * 7u) % (unsigned)kpH4), lane, ae4);
+        gemm_kpairs<1, 1, ENC_PF_SMALL>(lds, wp, kpH4, kpH4, (int)((blockIdx.x * 7u) % (unsigned)kpH4), lane, ae4);
         const int n = (part * 4 + wave) * 16 + (lane & 15);
         const double bn = a.bias[a.n_layers][n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t q = q0 + (lane >> 4) + 4 * r;          // (rows past B are scratch rows of e3)
-            a.e3[q * ENC_EMBED + n] = ae4[0][0][r] + bn;
+            st_xwg(a.e3 + q * ENC_EMBED + n, ae4[0][0][r] + bn);
         }
         return;
     }
     if (MODE == 3) {
         // the part's columns of the second layer: h2 = sin(acc + b) (location_encoder.py:147-150, w0 = 1)
         __syncthreads();
+        ENC_STAMP(10);
+        if (wave >= NW) return;                              // (encoder_tile_kernel: 16 waves fill the LDS, NW compute)
         const int kpH3 = a.H >> 3;
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[1]) +
                           ((int64_t)(part * (a.part2_cols >> 4) + wave * NTW) * kpH3) * 64 + lane;
-        gemm_kpairs<NTW, QT>(lds, wp, kpH3, kpH3, (int)((blockIdx.x * 7u) % (unsigned)kpH3), lane, acc);
+        gemm_kpairs<NTW, QT, PF>(lds, wp, kpH3, kpH3, (int)((blockIdx.x * 7u) % (unsigned)kpH3), lane, acc);
+        ENC_STAMP(11);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int n = part * a.part2_cols + (wave * NTW + i) * 16 + (lane & 15);
@@ -460,7 +497,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t q = q0 + (lane >> 4) + 4 * r;      // (rows past B are scratch rows of h2)
-                a.h2[q * a.H + n] = sin(acc[0][i][r] + bn);
+                st_xwg(a.h2 + q * a.H + n, sin(acc[0][i][r] + bn));
             }
         }
         return;
@@ -481,7 +518,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
                 for (int qt = 0; qt < QT; ++qt) acc[qt][i] = f64x4{0, 0, 0, 0};
             const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[layer + 1]) +
                               ((int64_t)(wave * NTW) * kpH) * 64 + lane;
-            gemm_kpairs<NTW, QT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, acc);
+            gemm_kpairs<NTW, QT, PF>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, acc);
         }
     }
 
@@ -495,7 +532,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
     {
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) +
                           ((int64_t)(wave * EW) * kpH) * 64 + lane;
-        gemm_kpairs<EW, QT>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, ae);
+        gemm_kpairs<EW, QT, PF>(lds, wp, kpH, kpH, (int)((blockIdx.x * 7u) % (unsigned)kpH), lane, ae);
     }
     const double* bl = a.bias[a.n_layers];
     double ss[QT][4];
@@ -588,14 +625,10 @@ __global__ __launch_bounds__(256, 1) void encoder_l3_part_kernel(EncArgs a) {
 
 // e = e3 / |e3| (range.py:212), its float32 copy, the raw output if asked for, and the query's unit
 // vector (float64 trig, then .float(): range.py:225-231, utils.py:11-16).  One wave per query.
-__global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= a.B) return;
+__device__ __forceinline__ void encoder_norm_query(const EncArgs& a, int64_t q, int lane) {
     double v[4], ss = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = a.e3[q * ENC_EMBED + 64 * i + lane]; ss += v[i] * v[i]; }
-    // (the summation order of the one-kernel encoder: 16 columns of an n-tile across lanes, n-tiles in order)
+    for (int i = 0; i < 4; ++i) { v[i] = ld_xwg(a.e3 + q * ENC_EMBED + 64 * i + lane); ss += v[i] * v[i]; }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) ss += __shfl_xor(ss, off);
     const double nrm = sqrt(ss);
@@ -613,6 +646,98 @@ __global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
         const double cl = cos(lat);
         *reinterpret_cast<float4*>(a.xq + q * 4) = make_float4((float)(cl * cos(lon)), (float)(cl * sin(lon)), (float)sin(lat), 0.f);
     }
+}
+__global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);
+}
+
+// ONE launch for ONE 16-query tile (the latency regime: up to 16 queries).  As separate launches the
+// small-batch encoder costs ~110 us: the first layer's part kernel 33 us, then ONE workgroup's chain
+// over the rest (90 us) - and every further launch that would spread that chain costs 10-20 us of its
+// own (dispatch + 4-6 us before a kernel's first memory access returns).  Here the workgroups of the
+// first layer stay and meet at counters (phase stamps of a -DRANGE_EXP_ENC_STAMPS build, round 3: the
+// first layer 12.5 us; summing + activating its 16 x H outputs 58 us when 256 threads of a workgroup
+// did it alone - one memory round trip and one float64 sin per element and thread):
+//   phase 1  all workgroups (n_parts x n_kparts): first layer, one column part x one K range (MODE 1)
+//   phase 2  the first 16 H / 1024 workgroups: sum of the K parts + bias, sin(30 .): ONE element per thread
+//   phase 3  workgroups [0, n_parts2): second layer, 64 columns each (MODE 3 on the activated input)
+//   phase 4  workgroups [0, 4): last layer, 64 outputs each (MODE 4)
+//   phase 5  workgroup 0: norm, float32 copy, query unit vectors - a wave per query
+// Hand-off between phases (guide: Guideline 16 / visibility table, first row): the buffers are
+// written through (st_xwg), every storing wave waits vmcnt(0), workgroup barrier, ONE lane of the
+// workgroup increments the phase's counter; a consuming workgroup polls it (sc1 load) and reads
+// the buffers with sc1 loads (ld_xwg) behind a barrier that lane joins.  All workgroups are
+// resident (grid <= CUs, one per CU) and arrive before they wait.  The counters wrap to zero by
+// themselves: arrivals + one increment per consumer = the wrap limit of the atomic inc.
+constexpr uint32_t ENC_SPIN_LIMIT = 1u << 21;
+// returns false for a workgroup that has no part in the next phase (or whose wait gave up)
+__device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (every wave: its stores have completed)
+    __syncthreads();
+    if (threadIdx.x == 0) atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));
+    if (!consumer) return false;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (uint32_t spins = 0;
+             __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)n_prod; ++spins) {
+            if (spins > ENC_SPIN_LIMIT) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));     // (the last consumer's increment wraps the counter to 0)
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+template <int NTP, int NWP>
+__global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (a word of the norm's reduction area, unused by the part bodies: a static __shared__ variable
+    // would shift the dynamic LDS base off its 16-byte alignment)
+    int* flag = reinterpret_cast<int*>(reinterpret_cast<double*>(smem) + a.lds_main_doubles);
+    const int n_wg = a.n_parts * a.n_kparts;                 // == gridDim.x
+    const int part = blockIdx.x / a.n_kparts, kpart = blockIdx.x - part * a.n_kparts;
+    const int b = (int)blockIdx.x;
+    ENC_STAMP(0);
+    {
+        EncArgs a1 = a;
+        a1.h1a = nullptr;
+        encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a1, 0, smem, part, kpart);
+    }
+    ENC_STAMP(1);
+    // ---- h1a = sin(30 (sum of the K parts + b)) (location_encoder.py:119, 147-150): one element per thread
+    const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
+    if (!enc_phase_sync(a.sync, n_wg, n_act, b < n_act, flag)) return;
+    ENC_STAMP(2);
+    {
+        const int e = b * (int)blockDim.x + (int)threadIdx.x;
+        if (e < 16 * a.H) {
+            const int k = e % a.H;
+            double v = ld_xwg(a.h1 + e);                   // (rows = 16: plane kp of h1 starts at kp * 16 * H)
+            for (int kp = 1; kp < a.n_kparts; ++kp) v += ld_xwg(a.h1 + (int64_t)kp * 16 * a.H + e);
+            st_xwg(a.h1a + e, sin(30.0 * (v + a.bias[0][k])));
+        }
+    }
+    ENC_STAMP(3);
+    // ---- second layer on the first n_parts2 workgroups
+    if (!enc_phase_sync(a.sync + 64, n_act, a.n_parts2, b < a.n_parts2, flag)) return;
+    ENC_STAMP(4);
+    encoder_body<1, 4, 1, 3>(a, 0, smem, b);
+    ENC_STAMP(5);
+    // ---- last layer on workgroups 0..3
+    if (!enc_phase_sync(a.sync + 128, a.n_parts2, 4, b < 4, flag)) return;
+    ENC_STAMP(6);
+    encoder_body<4, 4, 1, 4>(a, 0, smem, b);
+    ENC_STAMP(7);
+    // ---- norm on workgroup 0: a wave per query
+    if (!enc_phase_sync(a.sync + 192, 4, 1, b == 0, flag)) return;
+    {
+        const int64_t q = threadIdx.x >> 6;
+        if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);
+    }
+    ENC_STAMP(8);
 }
 
 template <int NT, int NW>

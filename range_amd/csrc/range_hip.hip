@@ -96,7 +96,10 @@ struct range_ctx {
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
-    DevBuf<double> ws_ehat64, ws_h1, ws_h2, ws_e3;
+    DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
+    DevBuf<uint32_t> ws_enc_sync;   // encoder_tile_kernel: 4 phase counters, 64 words apart
+    bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
+    bool enc_sync_zeroed = false;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
@@ -167,6 +170,54 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     const int ntp = a.part_cols / 64;
     int rc = RANGE_OK;
     ProfScope ps(c, RANGE_PROF_ENCODER, s);
+    // one 16-query tile: all four phases in ONE launch (encoder_tile_kernel) where the first layer's
+    // workgroups are enough to carry the later phases (H / 64 of them the second layer, 4 the last)
+    if (tiles == 1 && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 &&
+        S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024) && S * KP <= c->n_cu) {
+        if (c->ws_h2.ensure((size_t)16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)16 * a.H) != hipSuccess ||
+            c->ws_e3.ensure((size_t)16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(256) != hipSuccess)
+            return fail(RANGE_ERR_NOMEM, "out of device memory");
+        // (the counters wrap to zero by themselves; zeroed once, and again after a launch whose
+        // spin gave up - it leaves word 191 set, read back with the next synchronising call)
+        if (!c->enc_sync_zeroed) {
+            HIP_TRY(hipMemsetAsync(c->ws_enc_sync.p, 0, 256 * 4, s));
+            c->enc_sync_zeroed = true;
+        }
+        a.h2 = c->ws_h2.p;
+        a.h1a = c->ws_h1a.p;
+        a.e3 = c->ws_e3.p;
+        a.sync = c->ws_enc_sync.p;
+        a.n_parts2 = a.H / 64;
+        a.part2_cols = 64;
+        a.rest_from = 1;
+#define RANGE_ENC_TILE(NTP, NWP)                                                               \
+    case NTP:                                                                                  \
+        rc = set_dyn_lds(encoder_tile_kernel<NTP, NWP>, lds);                                  \
+        if (rc) return rc;                                                                     \
+        hipLaunchKernelGGL((encoder_tile_kernel<NTP, NWP>), dim3(S * KP), dim3(ENC_PART_WAVES * 64), lds, s, a); \
+        break;
+        switch (ntp) {
+            RANGE_ENC_TILE(1, 4)
+            RANGE_ENC_TILE(2, 8)
+            RANGE_ENC_TILE(4, 8)
+            RANGE_ENC_TILE(8, 16)
+            default: return fail(RANGE_ERR_INVALID, "internal: encoder part width %d", a.part_cols);
+        }
+#undef RANGE_ENC_TILE
+        HIP_TRY(hipGetLastError());
+#ifdef RANGE_EXP_ENC_STAMPS
+        if (std::getenv("RANGE_ENC_STAMPS")) {
+            unsigned long long h[12];
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(h, c->ws_e3.p + 16 * ENC_EMBED, sizeof h, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "encoder_tile stamps (us after start):");
+            for (int i = 1; i < 12; ++i) std::fprintf(stderr, " %d: %.1f", i, (double)(h[i] - h[0]) * 0.01);
+            std::fprintf(stderr, "  [1 first layer, 2 sync, 3 activation, 4 sync, 5 second layer (10 its input in LDS, 11 its products), "
+                         "6 sync, 7 last layer, 8 sync + norm]\n");
+        }
+#endif
+        return RANGE_OK;
+    }
 #define RANGE_ENC_PART(NTP, NWP)                                                               \
     case NTP:                                                                                  \
         rc = set_dyn_lds(encoder_l1_part_kernel<NTP, NWP>, lds);                               \
@@ -446,6 +497,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_ENC_SPLIT")) c->enc_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT3")) c->enc_split3 = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_FUSED")) c->enc_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_TAIL")) c->enc_tail_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';

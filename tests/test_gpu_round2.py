@@ -337,10 +337,10 @@ def test_small_batches_take_one_pass_over_the_bank(N, monkeypatch):
         x = torch.from_numpy(q).cuda()
         for model, name, beta in ((_native.MODEL_RANGE_PLUS, "RANGE+", 0.5), (_native.MODEL_RANGE_PLUS, "RANGE+", 0.0),
                                   (_native.MODEL_RANGE_PLUS, "RANGE+", 1.0), (_native.MODEL_RANGE, "RANGE", 1.0)):
+            eng.profile_enable(True)
             out = eng.forward(x, model, beta).cpu().numpy()
-            qt, ns = eng.last_geometry()
-            if N >= 1000:                                                         # which route ran
-                assert (qt == 1 and ns == min(256, (N + 15) // 16)) == (B <= 16)
+            assert eng.profile_read(_native.PROF_SCAN_STATS)[1] == (0 if B <= 16 else 1)   # which route ran: no pass 1
+            eng.profile_enable(False)
             ref64 = O.retrieve64(out[:, 1024:], q, obank, name, beta)
             np.testing.assert_allclose(out[:, :1024], ref64, rtol=0, atol=2e-5)
             np.testing.assert_allclose(out, O.retrieve(out[:, 1024:], q, obank, name, beta), rtol=0, atol=1e-4)
