@@ -142,12 +142,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int NTW, int QT, int PF = ENC_PF>
 __device__ __forceinline__ void gemm_kpairs(const double* lds, const f64x2* wp, int kpairs,
                                             int64_t kp_stride, int kp_rot, int lane,
-                                            f64x4 (&acc)[QT][NTW]) {
+                                            f64x4 (&acc)[QT][NTW], int ks_base = 0) {
     auto rot = [&](int i) __attribute__((always_inline)) {
         i += kp_rot;
         return i >= kpairs ? i - kpairs : i;
     };
-    const int ks_base = 0;
+    // (ks_base: first k-step of the LDS operand when wp points into the middle of the K range)
     f64x2 bq[PF][NTW];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
@@ -466,12 +466,25 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         // 64 outputs of the last layer (Identity activation, location_encoder.py:95-96, 112): one n-tile
         // per wave (4 waves), raw value + bias to e3; the norm follows in encoder_norm_kernel
         __syncthreads();
-        if (wave >= 4) return;                               // (encoder_tile_kernel: 16 waves fill the LDS, 4 compute)
         const int kpH4 = a.H >> 3;
         f64x4 ae4[1][1] = {{f64x4{0, 0, 0, 0}}};
-        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) + ((int64_t)(part * 4 + wave) * kpH4) * 64 + lane;
-        gemm_kpairs<1, 1, ENC_PF_SMALL>(lds, wp, kpH4, kpH4, (int)((blockIdx.x * 7u) % (unsigned)kpH4), lane, ae4);
-        const int n = (part * 4 + wave) * 16 + (lane & 15);
+        // encoder_tile_kernel runs this with 16 waves: 4 n-tiles x 4 quarters of K, the quarters' partial
+        // tiles summed through the spare half of the activation area (a wave alone walks 64 k-pairs in 8 us)
+        const int KS = (16 * a.H + 3 * 4 * 256 <= a.lds_main_doubles && (int)(blockDim.x >> 6) >= 16 && (kpH4 & 3) == 0) ? 4 : 1;
+        const int wn = wave & 3, kq = wave >> 2;
+        if (kq >= KS) return;
+        const int kcnt = kpH4 / KS;
+        const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[a.n_layers]) +
+                          ((int64_t)(part * 4 + wn) * kpH4 + (int64_t)kq * kcnt) * 64 + lane;
+        gemm_kpairs<1, 1, ENC_PF_SMALL>(lds, wp, kcnt, kpH4, (int)((blockIdx.x * 7u) % (unsigned)kcnt), lane, ae4, 2 * kq * kcnt);
+        if (KS > 1) {
+            f64x4* px = reinterpret_cast<f64x4*>(lds + 16 * a.H);
+            if (kq > 0) px[((kq - 1) * 4 + wn) * 64 + lane] = ae4[0][0];
+            __syncthreads();
+            if (kq > 0) return;
+            for (int kk = 0; kk < KS - 1; ++kk) ae4[0][0] += px[(kk * 4 + wn) * 64 + lane];
+        }
+        const int n = (part * 4 + wn) * 16 + (lane & 15);
         const double bn = a.bias[a.n_layers][n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -484,15 +497,26 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         // the part's columns of the second layer: h2 = sin(acc + b) (location_encoder.py:147-150, w0 = 1)
         __syncthreads();
         ENC_STAMP(10);
-        if (wave >= NW) return;                              // (encoder_tile_kernel: 16 waves fill the LDS, NW compute)
         const int kpH3 = a.H >> 3;
+        // (encoder_tile_kernel runs this with 16 waves for NW = 4: 4 quarters of K per n-tile, as in MODE 4)
+        const int KS = (NTW == 1 && 16 * a.H + 3 * NW * 256 <= a.lds_main_doubles && (int)(blockDim.x >> 6) >= 4 * NW && (kpH3 & 3) == 0) ? 4 : 1;
+        const int wn = wave % NW, kq = wave / NW;
+        if (kq >= KS) return;
+        const int kcnt = kpH3 / KS;
         const f64x2* wp = reinterpret_cast<const f64x2*>(a.wp[1]) +
-                          ((int64_t)(part * (a.part2_cols >> 4) + wave * NTW) * kpH3) * 64 + lane;
-        gemm_kpairs<NTW, QT, PF>(lds, wp, kpH3, kpH3, (int)((blockIdx.x * 7u) % (unsigned)kpH3), lane, acc);
+                          ((int64_t)(part * (a.part2_cols >> 4) + wn * NTW) * kpH3 + (int64_t)kq * kcnt) * 64 + lane;
+        gemm_kpairs<NTW, QT, PF>(lds, wp, kcnt, kpH3, (int)((blockIdx.x * 7u) % (unsigned)kcnt), lane, acc, 2 * kq * kcnt);
+        if (KS > 1) {
+            f64x4* px = reinterpret_cast<f64x4*>(lds + 16 * a.H);
+            if (kq > 0) px[((kq - 1) * NW + wn) * 64 + lane] = acc[0][0];
+            __syncthreads();
+            if (kq > 0) return;
+            for (int kk = 0; kk < KS - 1; ++kk) acc[0][0] += px[(kk * NW + wn) * 64 + lane];
+        }
         ENC_STAMP(11);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const int n = part * a.part2_cols + (wave * NTW + i) * 16 + (lane & 15);
+            const int n = part * a.part2_cols + (wn * NTW + i) * 16 + (lane & 15);
             const double bn = a.bias[1][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -99,7 +99,6 @@ struct range_ctx {
     DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
     DevBuf<uint32_t> ws_enc_sync;   // encoder_tile_kernel: 4 phase counters, 64 words apart
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
-    bool enc_sync_zeroed = false;
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
@@ -177,12 +176,10 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         if (c->ws_h2.ensure((size_t)16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)16 * a.H) != hipSuccess ||
             c->ws_e3.ensure((size_t)16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(256) != hipSuccess)
             return fail(RANGE_ERR_NOMEM, "out of device memory");
-        // (the counters wrap to zero by themselves; zeroed once, and again after a launch whose
-        // spin gave up - it leaves word 191 set, read back with the next synchronising call)
-        if (!c->enc_sync_zeroed) {
-            HIP_TRY(hipMemsetAsync(c->ws_enc_sync.p, 0, 256 * 4, s));
-            c->enc_sync_zeroed = true;
-        }
+        // (the counters wrap to zero by themselves, but a launch whose bounded spin gave up would leave
+        // them poisoned for good: zeroed in front of every launch - 2 us of a ~55 us kernel - as the
+        // guide asks of every polled word)
+        HIP_TRY(hipMemsetAsync(c->ws_enc_sync.p, 0, 256 * 4, s));
         a.h2 = c->ws_h2.p;
         a.h1a = c->ws_h1a.p;
         a.e3 = c->ws_e3.p;
