@@ -115,7 +115,7 @@ def spawn_ranks(a) -> int:
 # rank process
 # ------------------------------------------------------------------------------------------------
 def encoder_params(L, H):
-    from range_amd import synth
+    from tools import synth
     from range_amd.ckpt import EncoderParams
     w = synth.make_encoder_weights(L, H, 256, 2, 1234)
     return w, EncoderParams(L, H, 2, 256, "analytic",
@@ -140,7 +140,7 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     import numpy as np
     import torch
     from oracle import range_oracle as O     # checker / baseline only
-    from range_amd import synth
+    from tools import synth
     locs, vals, keys = bank_arrays
     obank = O.prep_bank(locs, vals, keys)
     q = synth.make_queries(n_sample, seed=7, lat_max=90.0)
@@ -211,7 +211,8 @@ def main():
     import numpy as np
     import torch
 
-    from range_amd import _native, synth
+    from range_amd import _native
+    from tools import synth
     from range_amd.bank import prepare_bank
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

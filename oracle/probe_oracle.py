@@ -28,7 +28,7 @@ held-out score (first one on ties), and refit on all rows:
 * scores: R^2 (uniform average over target columns) / accuracy.
 
 Pinned by tests/golden/probe_*.npz: values returned by the reference's own ``evaluate_npz`` run in
-this container on the seeded tasks of range_amd.synth.PROBE_CASES (tests/golden/make_golden_next.py)
+this container on the seeded tasks of tools.synth.PROBE_CASES (tests/golden/make_golden_next.py)
 and, in tests/test_probe_cpu.py, by scikit-learn itself.
 """
 from __future__ import annotations

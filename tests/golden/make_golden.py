@@ -23,7 +23,7 @@ bytecode is written, no reference source is copied into this repository):
   .callbacks/.cli), timm, torchgeo(.models/.datasets.geo), rasterio, torchvision(.transforms),
   albumentations(.core.transforms_interface/.pytorch), geoclip/rshf if requested lazily.
 
-Inputs are synthetic and seeded (range_amd.synth): fixtures hold the seeds, the query coordinates
+Inputs are synthetic and seeded (tools.synth): fixtures hold the seeds, the query coordinates
 and the reference's outputs, not the multi-MB weights/banks, which tests rebuild from the seeds.
 """
 from __future__ import annotations
@@ -49,7 +49,7 @@ SAT = os.path.join(REF, "range/location_models/satclip")
 PE_DIR = os.path.join(SAT, "positional_encoding")
 sys.path.insert(0, REPO)
 
-from range_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 
 
 # ----------------------------------------------------------------------------------------------

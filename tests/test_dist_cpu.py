@@ -14,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import range_oracle as O
-from range_amd import synth
+from tools import synth
 from range_amd.dist import ShardedRange, shard_rows
 
 LOG2E = 1.4426950408889634

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle import range_oracle as O
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 
 pytestmark = pytest.mark.gpu
 

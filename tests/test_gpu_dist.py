@@ -25,7 +25,8 @@ def _free_port():
 def _rank(rank, world, port, ret):
     import torch.distributed as dist
     from oracle import range_oracle as O
-    from range_amd import _native, synth
+    from range_amd import _native
+    from tools import synth
     from range_amd.bank import prepare_bank
     from range_amd.dist import ShardedRange, shard_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -24,7 +24,8 @@ import pytest
 import torch
 
 from oracle import range_oracle as O
-from range_amd import load_model, synth
+from range_amd import load_model
+from tools import synth
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

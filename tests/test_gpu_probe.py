@@ -10,7 +10,7 @@ import torch
 
 from oracle import probe_oracle as po
 from range_amd import evaluate as ev
-from range_amd import synth
+from tools import synth
 from range_amd._probe_native import ProbeEngine
 
 pytestmark = pytest.mark.gpu

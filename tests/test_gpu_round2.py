@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import range_oracle as O
-from range_amd import _native, sh_table, synth
+from range_amd import _native, sh_table
+from tools import synth
 from range_amd.bank import prepare_bank
 
 pytestmark = pytest.mark.gpu

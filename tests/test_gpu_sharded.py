@@ -32,7 +32,7 @@ def _free_port():
 
 
 def _bank_arrays():
-    from range_amd import synth
+    from tools import synth
     locs, vals, keys = synth.make_bank(N, 2024)
     vals = vals.copy()
     vals[:, 0] = 1.0            # constant columns: reproduced iff the weights of a row sum to one over ALL shards
@@ -55,7 +55,8 @@ def _sample_check(out_rows, q_rows, obank, w, betas):
 def _rank(rank, world, port, ck, rbank, tmp, ret):
     import torch.distributed as dist
     from oracle import range_oracle as O
-    from range_amd import load_model, synth
+    from range_amd import load_model
+    from tools import synth
     from range_amd.save import save_embeddings
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -132,7 +133,7 @@ def _rank(rank, world, port, ck, rbank, tmp, ret):
 
 
 def test_sharded_product_entry_at_c4_c5_shapes(tmp_path):
-    from range_amd import synth
+    from tools import synth
     from range_amd.bank import prepare_bank
     from range_amd.bankfile import write_bankfile
     ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
@@ -144,7 +145,8 @@ def test_sharded_product_entry_at_c4_c5_shapes(tmp_path):
 
 
 def test_load_model_shards_needs_a_process_group(tmp_path):
-    from range_amd import load_model, synth
+    from range_amd import load_model
+    from tools import synth
     ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=10, hidden=64, seed=1)
     db = synth.write_bank(str(tmp_path / "db.npz"), 300, seed=3)
     with pytest.raises(RuntimeError, match="torch.distributed"):

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import range_oracle as O
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import load_bank, prepare_bank
 from range_amd.ckpt import read_checkpoint
 from range_amd.load_model import load_model

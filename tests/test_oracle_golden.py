@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import range_oracle as O
-from range_amd import synth
+from tools import synth
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 ENC = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "enc_*.npz")))

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import probe_oracle as po  # noqa: E402
 from oracle import range_oracle as ro  # noqa: E402
-from range_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden")
 

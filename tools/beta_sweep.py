@@ -8,7 +8,8 @@ import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from range_amd import load_model, synth
+from range_amd import load_model
+from tools import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 betas = (0.0, 0.25, 0.5, 0.75, 1.0)

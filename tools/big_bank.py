@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 from oracle import range_oracle as O
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 
 args = [int(v) for v in sys.argv[1:] if v.isdigit()]
 N = args[0] if args else 1_000_000

@@ -9,7 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from range_amd import _native, sh_table, synth
+from range_amd import _native, sh_table
+from tools import synth
 
 dev = torch.device("cuda:0")
 w = synth.make_encoder_weights(40, 512, 256, 2, 1234)

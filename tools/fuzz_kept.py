@@ -6,7 +6,8 @@ kinds of context.  Usage: python tools/fuzz_kept.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import prepare_bank
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40

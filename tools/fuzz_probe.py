@@ -5,7 +5,8 @@ import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import probe_oracle as po          # the checker
-from range_amd import evaluate as ev, synth
+from range_amd import evaluate as ev
+from tools import synth
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

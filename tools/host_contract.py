@@ -6,7 +6,8 @@ import os, sys, time, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np, torch
-    from range_amd import _native, synth
+    from range_amd import _native
+    from tools import synth
     from range_amd.bank import prepare_bank
     from range_amd.ckpt import EncoderParams
     w = synth.make_encoder_weights(40, 512, 256, 2, 1234)

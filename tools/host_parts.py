@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import prepare_bank
 from range_amd.range import sh_table_for
 dev = torch.device("cuda:0")

@@ -6,7 +6,8 @@ RANGE_SMALL_FORWARD=0 sends them through the two-pass kernels for comparison).""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from range_amd import _native, synth, sh_table
+from range_amd import _native, sh_table
+from tools import synth
 from range_amd.bank import prepare_bank
 
 dev = torch.device("cuda:0")

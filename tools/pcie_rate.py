@@ -4,7 +4,8 @@ its synchronous D2H, as the reference's caller does; (b) range_amd.save.Embeddin
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from range_amd import load_model, synth
+from range_amd import load_model
+from tools import synth
 from range_amd.save import EmbeddingPipeline
 
 tmp = tempfile.mkdtemp()

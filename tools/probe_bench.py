@@ -25,7 +25,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from range_amd import evaluate as ev  # noqa: E402
-from range_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 
 F64_MFMA_PEAK = 78.6e12      # MI355X dense FP64 matrix, FLOP/s
 

@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from oracle import range_oracle as O
-from range_amd import _native, sh_table, synth
+from range_amd import _native, sh_table
+from tools import synth
 
 args = [v for v in sys.argv[1:] if v.isdigit()]
 B = int(args[0]) if args else 10000

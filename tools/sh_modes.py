@@ -7,7 +7,8 @@ encoder kernel's time for 10 000 queries in both."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from range_amd import _native, sh_table, synth
+from range_amd import _native, sh_table
+from tools import synth
 
 z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "latitude_L40_H512_n2.npz"))
 q, L, H = z["lonlat"], int(z["L"]), int(z["hidden"])

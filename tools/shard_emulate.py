@@ -21,7 +21,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from range_amd import _native, sh_table, synth
+from range_amd import _native, sh_table
+from tools import synth
 from range_amd.bank import prepare_bank
 
 dev = torch.device("cuda:0")

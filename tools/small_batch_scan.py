@@ -5,7 +5,8 @@ float32 keys instead of the default bf16 prefilter."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import prepare_bank
 N = 100000
 bank = prepare_bank(*synth.make_bank(N, 2024))

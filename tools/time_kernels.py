@@ -4,7 +4,8 @@ no result checks (usable with deliberately broken experiment builds)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import prepare_bank
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000

@@ -1,6 +1,7 @@
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from range_amd import _native, synth
+from range_amd import _native
+from tools import synth
 from range_amd.bank import prepare_bank
 bank = prepare_bank(*synth.make_bank(100000, 2024))
 eng = _native.HipEngine("cuda:0"); eng.set_bank(bank.keys, bank.values, bank.xyz)

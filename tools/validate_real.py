@@ -90,7 +90,8 @@ def main():
         print("no GPU visible: steps 1-3 only")
         return
     from oracle import range_oracle as O     # checker (test infrastructure)
-    from range_amd import load_model, synth
+    from range_amd import load_model
+    from tools import synth
     q = synth.make_queries(256, seed=1, lat_max=90.0)
     x = torch.from_numpy(q).to("cuda:0")
     obank = O.Bank(bank.keys, bank.values, bank.xyz)
