@@ -6,7 +6,8 @@ drops it - together 8 to 10 ms per 10 000 queries, a third of the GPU time of th
 keeps the memory of results the caller has DROPPED and hands it out again.
 
 Ownership is explicit (round 2 decided it from ``sys.getrefcount`` inside a finalizer - one
-interpreter change away from handing live memory out again): the pool owns plain memory blocks; a
+interpreter change away from handing live memory out again): the pool owns plain memory blocks
+(uint8 arrays nothing else refers to); a
 result is ``numpy.frombuffer`` over a per-result GUARD object (a ctypes array created
 ``from_buffer`` of the block), so the result, every slice / transpose / reshape of it and every
 ``torch.from_numpy`` tensor over it hold a reference chain to that guard - it is the ``base`` the
@@ -48,7 +49,7 @@ class HostResultPool:
     max_free_bytes = 1 << 30
 
     def __init__(self, enabled: bool | None = None):
-        self._free: Dict[int, List[bytearray]] = {}
+        self._free: Dict[int, List[np.ndarray]] = {}
         self._free_bytes = 0
         self._lock = threading.Lock()
         self.enabled = (os.environ.get("RANGE_HOST_POOL", "1") != "0") if enabled is None else enabled
@@ -66,7 +67,9 @@ class HostResultPool:
                 block = lst.pop()
                 self._free_bytes -= cap
         if block is None:
-            block = bytearray(cap)              # (zero pages: mapped on first touch, like np.empty)
+            # untouched pages (bytearray(cap) would memset them: 50 ms per 100 MB in one thread);
+            # their first-touch faults are spread over the library's copy threads when the result is filled
+            block = np.empty(cap, dtype=np.uint8)
         guard = (ctypes.c_ubyte * cap).from_buffer(block)
         fin = weakref.finalize(guard, self._give_back, block)
         fin.atexit = False
@@ -74,10 +77,10 @@ class HostResultPool:
         del guard                               # (only the array and its views hold it now)
         return out
 
-    def _give_back(self, block: bytearray) -> None:
+    def _give_back(self, block: np.ndarray) -> None:
         # called by the interpreter once the guard of a result is unreachable: nothing can see the
         # block's memory through numpy any more
-        cap = len(block)
+        cap = block.nbytes
         with self._lock:
             lst = self._free.setdefault(cap, [])
             if len(lst) < self.max_free_per_size and self._free_bytes + cap <= self.max_free_bytes:
