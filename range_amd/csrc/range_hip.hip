@@ -1534,6 +1534,20 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
             if (e == hipSuccess) e = hipEventRecord(sl.cop, c->copy_stream);
         }
     }
+    // Everything is enqueued and this thread would only wait now: the copy threads touch every page of
+    // the caller's array meanwhile (one write per 4 KB page; the data follows).  A fresh array is
+    // 25 000 untouched pages per 10 000 queries: faulted here, under the GPU's shadow, the fills
+    // below are plain copies - also the last part's, which the caller waits for.
+    if (e == hipSuccess && (size_t)B * row_bytes >= ((size_t)1 << 20)) {
+        char* base = (char*)out_host;
+        const size_t bytes = (size_t)B * row_bytes;
+        c->pool->run([=](int t, int n) {
+            const size_t per = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+            const size_t lo = per * (size_t)t;
+            const size_t hi = lo + per < bytes ? lo + per : bytes;
+            for (size_t o = lo; o < hi; o += 4096) *(volatile char*)(base + o) = 0;
+        });
+    }
     const auto t_enq = std::chrono::steady_clock::now();
     double wait_s = 0.0, copy_s = 0.0;
     for (auto& sl : slabs) {
