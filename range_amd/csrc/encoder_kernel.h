@@ -732,10 +732,14 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     }
     ENC_STAMP(1);
     // ---- h1a = sin(30 (sum of the K parts + b)) (location_encoder.py:119, 147-150): one element per thread
+    // The first K = max(workgroups of any later phase) workgroups stay to the end and meet at every
+    // counter, whether or not a phase has work for them (narrow encoders: 2 workgroups activate, 2 run
+    // the second layer, but 4 the last one); the others leave after the first layer.
     const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
-    if (!enc_phase_sync(a.sync, n_wg, n_act, b < n_act, flag)) return;
+    const int K = max(max(n_act, a.n_parts2), 4);
+    if (!enc_phase_sync(a.sync, n_wg, K, b < K, flag)) return;
     ENC_STAMP(2);
-    {
+    if (b < n_act) {
         const int e = b * (int)blockDim.x + (int)threadIdx.x;
         if (e < 16 * a.H) {
             const int k = e % a.H;
@@ -746,17 +750,17 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     }
     ENC_STAMP(3);
     // ---- second layer on the first n_parts2 workgroups
-    if (!enc_phase_sync(a.sync + 64, n_act, a.n_parts2, b < a.n_parts2, flag)) return;
+    if (!enc_phase_sync(a.sync + 64, K, K, true, flag)) return;
     ENC_STAMP(4);
-    encoder_body<1, 4, 1, 3>(a, 0, smem, b);
+    if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, 0, smem, b);
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
-    if (!enc_phase_sync(a.sync + 128, a.n_parts2, 4, b < 4, flag)) return;
+    if (!enc_phase_sync(a.sync + 128, K, K, true, flag)) return;
     ENC_STAMP(6);
-    encoder_body<4, 4, 1, 4>(a, 0, smem, b);
+    if (b < 4) encoder_body<4, 4, 1, 4>(a, 0, smem, b);
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
-    if (!enc_phase_sync(a.sync + 192, 4, 1, b == 0, flag)) return;
+    if (!enc_phase_sync(a.sync + 192, K, 1, b == 0, flag)) return;
     {
         const int64_t q = threadIdx.x >> 6;
         if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);

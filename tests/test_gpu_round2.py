@@ -351,3 +351,58 @@ def test_small_batches_take_one_pass_over_the_bank(N, monkeypatch):
             np.testing.assert_allclose(out, other, rtol=0, atol=3e-6)
             host = eng.forward_host(x, model, beta)                            # the numpy contract, same route
             assert np.array_equal(host, out)
+
+
+def test_in_launch_handoffs_under_repetition(monkeypatch):
+    """The two kernels that hand data between workgroups INSIDE a launch - the top-k stream kernel
+    (candidate lists -> the merging workgroups; self-resetting sharded counters) and the one-tile
+    encoder (five phases meeting at wrap-around counters) - run hundreds of times back to back with
+    changing batch sizes and queries, each result compared with the same computation done as
+    separate launches (RANGE_TOPKS_FUSED=0 / RANGE_ENC_FUSED=0): a counter left non-zero, a stale
+    line or a lost increment shows as a wrong row or a hang (bounded spins: it would show as -1 / NaN
+    rows and an error from topk_stream_exact_count)."""
+    rng = np.random.default_rng(77)
+    N = 40_000
+    keys = rng.standard_normal((N, 256)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    L, H = 10, 128
+    w, ws, bs = _weights(L, H, 2, 3)
+    fused = _native.HipEngine("cuda:0")
+    monkeypatch.setenv("RANGE_TOPKS_FUSED", "0")
+    monkeypatch.setenv("RANGE_ENC_FUSED", "0")
+    apart = _native.HipEngine("cuda:0")
+    monkeypatch.delenv("RANGE_TOPKS_FUSED")
+    monkeypatch.delenv("RANGE_ENC_FUSED")
+    for e in (fused, apart):
+        e.set_keys(keys)
+        e.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sizes = (1, 16, 40, 200, 256, 300, 7, 64)
+    for it in range(240):
+        B = sizes[it % len(sizes)]
+        q = torch.nn.functional.normalize(torch.randn((B, 256), generator=g, device="cuda"), dim=1).contiguous()
+        k = (16, 5, 1)[it % 3]
+        av, ai = fused.topk_stream(q, k)
+        bv, bi = apart.topk_stream(q, k)
+        assert torch.equal(ai, bi) and torch.equal(av, bv), (it, B, k)
+        nq = 1 + it % 16
+        x = torch.stack([torch.rand(nq, generator=g, device="cuda", dtype=torch.float64) * 360 - 180,
+                         torch.rand(nq, generator=g, device="cuda", dtype=torch.float64) * 170 - 85], dim=1).contiguous()
+        e1 = fused.encode(x)
+        e2 = apart.encode(x)
+        assert float((e1[0] - e2[0]).abs().max()) < 1e-12 and torch.equal(e1[2], e2[2]), (it, nq)
+    assert fused.topk_stream_exact_count() == apart.topk_stream_exact_count()
+
+
+@pytest.mark.parametrize("L,H", [(10, 128), (12, 192), (40, 256), (20, 320), (40, 512), (16, 448)])
+def test_one_tile_encoder_over_widths(L, H):
+    """encoder_tile_kernel (one persistent launch for up to 16 queries) over hidden widths whose
+    phases need different numbers of workgroups (activation 2..8, second layer 2..8, last layer 4)."""
+    w, ws, bs = _weights(L, H, 2, 21)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_encoder(L, H, 2, 256, _native.SH_CLOSED_FORM, ws, bs)
+    for B in (1, 9, 16):
+        q = synth.make_queries(B, seed=B + H, lat_max=85.0)
+        e64, e32, xq = eng.encode(torch.from_numpy(q).cuda())
+        np.testing.assert_allclose(e64.cpu().numpy(), O.encode(q, w, L, "closed-form"), rtol=0, atol=2e-12)
+        np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1.2e-7)
