@@ -676,7 +676,8 @@ __global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
     if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);
 }
 
-// ONE launch for ONE 16-query tile (the latency regime: up to 16 queries).  As separate launches the
+// ONE launch for a FEW 16-query tiles (the latency regime: up to 512 queries), each tile on its own
+// workgroups.  As separate launches the
 // small-batch encoder costs ~110 us: the first layer's part kernel 33 us, then ONE workgroup's chain
 // over the rest (90 us) - and every further launch that would spread that chain costs 10-20 us of its
 // own (dispatch + 4-6 us before a kernel's first memory access returns).  Here the workgroups of the
@@ -721,14 +722,18 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // (a word of the norm's reduction area, unused by the part bodies: a static __shared__ variable
     // would shift the dynamic LDS base off its 16-byte alignment)
     int* flag = reinterpret_cast<int*>(reinterpret_cast<double*>(smem) + a.lds_main_doubles);
-    const int n_wg = a.n_parts * a.n_kparts;                 // == gridDim.x
-    const int part = blockIdx.x / a.n_kparts, kpart = blockIdx.x - part * a.n_kparts;
-    const int b = (int)blockIdx.x;
+    // several tiles run side by side, each with its own workgroups, counters and buffer rows
+    const int n_wg = a.n_parts * a.n_kparts;                 // workgroups per tile
+    const int tile = (int)blockIdx.x / n_wg, b = (int)blockIdx.x - tile * n_wg;
+    const int part = b / a.n_kparts, kpart = b - part * a.n_kparts;
+    const int64_t q0 = (int64_t)tile * 16;
+    const int64_t rows = ((a.B + 15) / 16) * 16;
+    uint32_t* sync = a.sync + tile * 256;
     ENC_STAMP(0);
     {
         EncArgs a1 = a;
         a1.h1a = nullptr;
-        encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a1, 0, smem, part, kpart);
+        encoder_body<NTP, NWP, 1, 1, ENC_PART_WAVES>(a1, q0, smem, part, kpart);
     }
     ENC_STAMP(1);
     // ---- h1a = sin(30 (sum of the K parts + b)) (location_encoder.py:119, 147-150): one element per thread
@@ -737,32 +742,33 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // the second layer, but 4 the last one); the others leave after the first layer.
     const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
     const int K = max(max(n_act, a.n_parts2), 4);
-    if (!enc_phase_sync(a.sync, n_wg, K, b < K, flag)) return;
+    if (!enc_phase_sync(sync, n_wg, K, b < K, flag)) return;
     ENC_STAMP(2);
     if (b < n_act) {
         const int e = b * (int)blockDim.x + (int)threadIdx.x;
         if (e < 16 * a.H) {
-            const int k = e % a.H;
-            double v = ld_xwg(a.h1 + e);                   // (rows = 16: plane kp of h1 starts at kp * 16 * H)
-            for (int kp = 1; kp < a.n_kparts; ++kp) v += ld_xwg(a.h1 + (int64_t)kp * 16 * a.H + e);
-            st_xwg(a.h1a + e, sin(30.0 * (v + a.bias[0][k])));
+            const int q = e / a.H, k = e - q * a.H;
+            const int64_t at = (q0 + q) * a.H + k;
+            double v = ld_xwg(a.h1 + at);
+            for (int kp = 1; kp < a.n_kparts; ++kp) v += ld_xwg(a.h1 + (int64_t)kp * rows * a.H + at);
+            st_xwg(a.h1a + at, sin(30.0 * (v + a.bias[0][k])));
         }
     }
     ENC_STAMP(3);
     // ---- second layer on the first n_parts2 workgroups
-    if (!enc_phase_sync(a.sync + 64, K, K, true, flag)) return;
+    if (!enc_phase_sync(sync + 64, K, K, true, flag)) return;
     ENC_STAMP(4);
-    if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, 0, smem, b);
+    if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, q0, smem, b);
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
-    if (!enc_phase_sync(a.sync + 128, K, K, true, flag)) return;
+    if (!enc_phase_sync(sync + 128, K, K, true, flag)) return;
     ENC_STAMP(6);
-    if (b < 4) encoder_body<4, 4, 1, 4>(a, 0, smem, b);
+    if (b < 4) encoder_body<4, 4, 1, 4>(a, q0, smem, b);
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
-    if (!enc_phase_sync(a.sync + 192, K, 1, b == 0, flag)) return;
+    if (!enc_phase_sync(sync + 192, K, 1, b == 0, flag)) return;
     {
-        const int64_t q = threadIdx.x >> 6;
+        const int64_t q = q0 + (threadIdx.x >> 6);
         if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);
     }
     ENC_STAMP(8);

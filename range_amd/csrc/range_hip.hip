@@ -169,17 +169,18 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     const int ntp = a.part_cols / 64;
     int rc = RANGE_OK;
     ProfScope ps(c, RANGE_PROF_ENCODER, s);
-    // one 16-query tile: all four phases in ONE launch (encoder_tile_kernel) where the first layer's
-    // workgroups are enough to carry the later phases (H / 64 of them the second layer, 4 the last)
-    if (tiles == 1 && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 &&
-        S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024) && S * KP <= c->n_cu) {
-        if (c->ws_h2.ensure((size_t)16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)16 * a.H) != hipSuccess ||
-            c->ws_e3.ensure((size_t)16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(256) != hipSuccess)
+    // up to 32 tiles (512 queries): all phases in ONE launch (encoder_tile_kernel), every tile on its own
+    // workgroups, where a tile's first-layer workgroups are enough to carry its later phases (H / 64 of
+    // them the second layer, 4 the last)
+    if (tiles <= 32 && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 &&
+        S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024) && tiles * S * KP <= c->n_cu) {
+        if (c->ws_h2.ensure((size_t)tiles * 16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)tiles * 16 * a.H) != hipSuccess ||
+            c->ws_e3.ensure((size_t)tiles * 16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(32 * 256) != hipSuccess)
             return fail(RANGE_ERR_NOMEM, "out of device memory");
         // (the counters wrap to zero by themselves, but a launch whose bounded spin gave up would leave
         // them poisoned for good: zeroed in front of every launch - 2 us of a ~55 us kernel - as the
         // guide asks of every polled word)
-        HIP_TRY(hipMemsetAsync(c->ws_enc_sync.p, 0, 256 * 4, s));
+        HIP_TRY(hipMemsetAsync(c->ws_enc_sync.p, 0, (size_t)tiles * 256 * 4, s));
         a.h2 = c->ws_h2.p;
         a.h1a = c->ws_h1a.p;
         a.e3 = c->ws_e3.p;
@@ -191,7 +192,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     case NTP:                                                                                  \
         rc = set_dyn_lds(encoder_tile_kernel<NTP, NWP>, lds);                                  \
         if (rc) return rc;                                                                     \
-        hipLaunchKernelGGL((encoder_tile_kernel<NTP, NWP>), dim3(S * KP), dim3(ENC_PART_WAVES * 64), lds, s, a); \
+        hipLaunchKernelGGL((encoder_tile_kernel<NTP, NWP>), dim3(tiles * S * KP), dim3(ENC_PART_WAVES * 64), lds, s, a); \
         break;
         switch (ntp) {
             RANGE_ENC_TILE(1, 4)
@@ -206,7 +207,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         if (std::getenv("RANGE_ENC_STAMPS")) {
             unsigned long long h[12];
             HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(h, c->ws_e3.p + 16 * ENC_EMBED, sizeof h, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h, c->ws_e3.p + 16 * ENC_EMBED, sizeof h, hipMemcpyDeviceToHost));   // (one tile: the stamps sit behind its 16 rows)
             std::fprintf(stderr, "encoder_tile stamps (us after start):");
             for (int i = 1; i < 12; ++i) std::fprintf(stderr, " %d: %.1f", i, (double)(h[i] - h[0]) * 0.01);
             std::fprintf(stderr, "  [1 first layer, 2 sync, 3 activation, 4 sync, 5 second layer (10 its input in LDS, 11 its products), "

@@ -385,7 +385,7 @@ def test_in_launch_handoffs_under_repetition(monkeypatch):
         av, ai = fused.topk_stream(q, k)
         bv, bi = apart.topk_stream(q, k)
         assert torch.equal(ai, bi) and torch.equal(av, bv), (it, B, k)
-        nq = 1 + it % 16
+        nq = 1 + (it * 23) % 530                      # 1 .. 530 queries: one to 32 tiles in one launch, and beyond
         x = torch.stack([torch.rand(nq, generator=g, device="cuda", dtype=torch.float64) * 360 - 180,
                          torch.rand(nq, generator=g, device="cuda", dtype=torch.float64) * 170 - 85], dim=1).contiguous()
         e1 = fused.encode(x)
@@ -396,12 +396,12 @@ def test_in_launch_handoffs_under_repetition(monkeypatch):
 
 @pytest.mark.parametrize("L,H", [(10, 128), (12, 192), (40, 256), (20, 320), (40, 512), (16, 448)])
 def test_one_tile_encoder_over_widths(L, H):
-    """encoder_tile_kernel (one persistent launch for up to 16 queries) over hidden widths whose
-    phases need different numbers of workgroups (activation 2..8, second layer 2..8, last layer 4)."""
+    """encoder_tile_kernel (one persistent launch for up to 8 tiles of 16 queries) over hidden widths
+    whose phases need different numbers of workgroups (activation 2..8, second layer 2..8, last layer 4)."""
     w, ws, bs = _weights(L, H, 2, 21)
     eng = _native.HipEngine("cuda:0")
     eng.set_encoder(L, H, 2, 256, _native.SH_CLOSED_FORM, ws, bs)
-    for B in (1, 9, 16):
+    for B in (1, 9, 16, 17, 50, 128, 300, 512):
         q = synth.make_queries(B, seed=B + H, lat_max=85.0)
         e64, e32, xq = eng.encode(torch.from_numpy(q).cuda())
         np.testing.assert_allclose(e64.cpu().numpy(), O.encode(q, w, L, "closed-form"), rtol=0, atol=2e-12)
