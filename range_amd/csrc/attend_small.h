@@ -1,4 +1,4 @@
-// The whole retrieval of a SMALL batch (up to 16 queries) in ONE pass over the bank.
+// The whole retrieval of a SMALL batch (up to 32 queries) in ONE pass over the bank.
 //
 // The two-pass kernels of attend_kernels.h are built for the FP32-MFMA-bound regime (64 queries per
 // workgroup, hundreds of workgroups per bank pass).  A handful of queries is the opposite regime:
@@ -13,10 +13,13 @@
 //     small_finalize_kernel sums the workgroups' partials in a fixed order, divides and blends
 //     (range.py:238).  Two products instead of pass 2's one combined weight - the extra MFMAs are
 //     free while HBM-bound, and it is the reference's own arithmetic (two P @ V products).
-//   * workgroup = 4 waves over the SAME 16 queries: wave w owns output columns [256 w, 256 w + 256)
-//     of both heads (32 accumulator tiles = 128 registers) and the k-slice [64 w, 64 w + 64) of the
-//     logits: 16 MFMAs per 16-row block and wave instead of 64; the four partial logit tiles meet
-//     in LDS (one workgroup barrier per block - the only one) and are summed in a fixed order.
+//   * workgroup = 4 waves over the SAME NQ x 16 queries (NQ = 1, or 2 for 17..32 queries): wave w
+//     owns output columns [256 w, 256 w + 256) of both heads (32 accumulator tiles = 128 registers
+//     per query tile) and the k-slice [64 w, 64 w + 64) of the logits: 16 MFMAs per 16-row block,
+//     query tile and wave instead of 64; the four partial logit tiles meet in LDS (one workgroup
+//     barrier per block - the only one) and are summed in a fixed order.  With two query tiles
+//     the kernel is at the MFMA / HBM ridge (290 MFMAs per block and wave = 3.9 us against 3.3 us
+//     of bank): 32 queries take the time of 16 and a little.
 //   * every wave streams ONLY what it uses, through wave-private LDS rings filled by LDS-DMA with
 //     hand-counted vmcnt waits: its 256-byte slice of the key rows (2 slots), its 1 KB slice of the
 //     value rows in 8-row halves (3 slots), the 16 locations.  Nothing else crosses waves, so the
@@ -38,9 +41,9 @@ struct SmallArgs {
     const float* values;   // (n_pad,1024)
     const float* ehat;     // (B,256)
     const float* xq;       // (B,4)
-    float* osum;           // (n_wg, 2 heads, 16 queries, 1024): un-normalised partial products
-    float* zsum;           // (n_wg, 16 queries, 2 heads): partial sums of the weights
-    int64_t B;             // 1..16
+    float* osum;           // (n_wg, 2 heads, 16 NQ queries, 1024): un-normalised partial products
+    float* zsum;           // (n_wg, 16 NQ queries, 2 heads): partial sums of the weights
+    int64_t B;             // 1..16 NQ
     int64_t n_valid;
     int32_t n_blocks;
     float k_sem, k_geo;    // tau * log2(e); k_geo = 0: no geographic head (plain RANGE)
@@ -53,10 +56,10 @@ constexpr int AS_X_BYTES = 256;                            // 16 rows x (x, y, z
 constexpr int AS_OFF_K = AS_VSLOTS * AS_V_BYTES;
 constexpr int AS_OFF_X = AS_OFF_K + 2 * AS_K_BYTES;
 constexpr int AS_WAVE_LDS = AS_OFF_X + 2 * AS_X_BYTES;     // 33 280 B per wave
-constexpr int AS_OFF_XBUF = 4 * AS_WAVE_LDS;               // partial logit tiles: 2 buffers x 4 waves x 1 KB
-constexpr int AS_LDS_BYTES = AS_OFF_XBUF + 2 * 4 * 1024;
+constexpr int AS_OFF_XBUF = 4 * AS_WAVE_LDS;               // partial logit tiles: 2 buffers x NQ x 4 waves x 1 KB
+constexpr int as_lds_bytes(int nq) { return AS_OFF_XBUF + 2 * nq * 4 * 1024; }
 
-template <bool GEO>
+template <bool GEO, int NQ>
 __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -73,18 +76,22 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 
     // ---- query operands (ordinary loads; pinned BEFORE the first LDS-DMA goes out: hipcc waits
     //      for them with vmcnt(0), which behind the ring's requests would wait for the ring)
-    f32x4 qf[4];
-    float xqv = 0.f;
-    {
-        const int64_t q = j < a.B ? j : a.B - 1;
+    f32x4 qf[NQ][4];
+    float xqv[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        const int64_t q = 16 * nq + j < a.B ? 16 * nq + j : a.B - 1;
         const f32x4* rowp = reinterpret_cast<const f32x4*>(a.ehat + q * KEY_DIM + 64 * wave);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = rowp[4 * s + g];
-        if (GEO) xqv = a.xq[q * 4 + g];
+        for (int s = 0; s < 4; ++s) qf[nq][s] = rowp[4 * s + g];
+        xqv[nq] = GEO ? a.xq[q * 4 + g] : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
-    asm volatile("" : "+v"(xqv));
+    for (int nq = 0; nq < NQ; ++nq) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[nq][s]));
+        asm volatile("" : "+v"(xqv[nq]));
+    }
 
     // ---- LDS-DMA of this wave's slices (sequence positions past the end re-fetch the last block:
     //      never consumed, they keep every wait below a constant)
@@ -134,12 +141,16 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
 
-    f32x4 acc[2][16];
+    f32x4 acc[NQ][2][16];
+    float z1[NQ], z2[NQ];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int nq = 0; nq < NQ; ++nq) {
+        z1[nq] = 0.f; z2[nq] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float z1 = 0.f, z2 = 0.f;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nq][h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float nm1 = -a.k_sem, nm2 = -a.k_geo;             // the constant shift m = tau * log2(e)
 
     for (int t = 0; t < nb; ++t) {
@@ -156,39 +167,47 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
         for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(kf[s]));
         asm volatile("" : "+v"(xa));
         issue_kx(t + 2);                                   // (the slots just read are free: wave-private)
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c[NQ], cg[NQ];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[s].x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[s].y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[s].z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[s].w, c, 0, 0, 0);
+        for (int nq = 0; nq < NQ; ++nq) {
+            c[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[nq][s].x, c[nq], 0, 0, 0);
+                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[nq][s].y, c[nq], 0, 0, 0);
+                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[nq][s].z, c[nq], 0, 0, 0);
+                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[nq][s].w, c[nq], 0, 0, 0);
+            }
+            cg[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (GEO) cg[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xqv[nq], cg[nq], 0, 0, 0);
         }
-        f32x4 cg = {0.f, 0.f, 0.f, 0.f};
-        if (GEO) cg = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xqv, cg, 0, 0, 0);
         // ---- the four k-slices meet: partial tiles through LDS, summed in a fixed order
-        f32x4* xb = xbuf + (t & 1) * 256;
-        xb[wave * 64 + lane] = c;
+        f32x4* xb = xbuf + (t & 1) * (NQ * 256);
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) xb[(nq * 4 + wave) * 64 + lane] = c[nq];
         __syncthreads();
-        f32x4 sv = xb[lane];
-        sv += xb[64 + lane];
-        sv += xb[128 + lane];
-        sv += xb[192 + lane];
         // ---- un-normalised weights of both heads (pad rows of the bank's last block: 0)
         const uint32_t row0 = (uint32_t)(b0 + t) * BLK;
-        float p1[4], p2[4];
+        float p1[NQ][4], p2[NQ][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = row0 + prow[r] < (uint32_t)a.n_valid;
-            const float e1 = __builtin_amdgcn_exp2f(fmaf(sv[r], a.k_sem, nm1));
-            p1[r] = ok ? e1 : 0.f;
-            z1 += p1[r];
-            if (GEO) {
-                const float e2 = __builtin_amdgcn_exp2f(fmaf(cg[r], a.k_geo, nm2));
-                p2[r] = ok ? e2 : 0.f;
-                z2 += p2[r];
-            } else {
-                p2[r] = 0.f;
+        for (int nq = 0; nq < NQ; ++nq) {
+            f32x4 sv = xb[(nq * 4 + 0) * 64 + lane];
+            sv += xb[(nq * 4 + 1) * 64 + lane];
+            sv += xb[(nq * 4 + 2) * 64 + lane];
+            sv += xb[(nq * 4 + 3) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = row0 + prow[r] < (uint32_t)a.n_valid;
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(sv[r], a.k_sem, nm1));
+                p1[nq][r] = ok ? e1 : 0.f;
+                z1[nq] += p1[nq][r];
+                if (GEO) {
+                    const float e2 = __builtin_amdgcn_exp2f(fmaf(cg[nq][r], a.k_geo, nm2));
+                    p2[nq][r] = ok ? e2 : 0.f;
+                    z2[nq] += p2[nq][r];
+                } else {
+                    p2[nq][r] = 0.f;
+                }
             }
         }
         // ---- P @ V, half by half: 2 rows per lane group and half, 4 column groups of 64, a
@@ -215,9 +234,19 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
                 for (int gg = 0; gg < 4; ++gg) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        acc[0][gg * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1[r], vb[rr][gg][u], acc[0][gg * 4 + u], 0, 0, 0);
-                        if (GEO)
-                            acc[1][gg * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(p2[r], vb[rr][gg][u], acc[1][gg * 4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int nq = 0; nq < NQ; ++nq) {
+                            if (NQ * (GEO ? 2 : 1) > 2) {
+                                // 256 accumulator registers: pinned to the AGPR file (mfma_a; left to
+                                // the builtin hipcc moved 600 registers per block between the files)
+                                mfma_a(acc[nq][0][gg * 4 + u], p1[nq][r], vb[rr][gg][u]);
+                                if (GEO) mfma_a(acc[nq][1][gg * 4 + u], p2[nq][r], vb[rr][gg][u]);
+                            } else {
+                                acc[nq][0][gg * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1[nq][r], vb[rr][gg][u], acc[nq][0][gg * 4 + u], 0, 0, 0);
+                                if (GEO)
+                                    acc[nq][1][gg * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(p2[nq][r], vb[rr][gg][u], acc[nq][1][gg * 4 + u], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -227,23 +256,29 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 
     // ---- this workgroup's partials: accumulator tile (gg, u), register r of lane (n = j, mg = g)
     //      = query 4 g + r, column 256 w + 64 gg + 4 j + u: the 4 tiles u are 4 consecutive columns
-    float* ob = a.osum + (int64_t)blockIdx.x * (2 * 16 * VAL_DIM);
+    constexpr int QC = 16 * NQ;
+    float* ob = a.osum + (int64_t)blockIdx.x * (2 * QC * VAL_DIM);
 #pragma unroll
-    for (int h = 0; h < (GEO ? 2 : 1); ++h) {
+    for (int nq = 0; nq < NQ; ++nq) {
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
+        for (int h = 0; h < (GEO ? 2 : 1); ++h) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 o = {acc[h][gg * 4 + 0][r], acc[h][gg * 4 + 1][r], acc[h][gg * 4 + 2][r], acc[h][gg * 4 + 3][r]};
-                *reinterpret_cast<f32x4*>(ob + ((int64_t)h * 16 + 4 * g + r) * VAL_DIM + 256 * wave + 64 * gg + 4 * j) = o;
+            for (int gg = 0; gg < 4; ++gg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 o = {acc[nq][h][gg * 4 + 0][r], acc[nq][h][gg * 4 + 1][r], acc[nq][h][gg * 4 + 2][r],
+                                     acc[nq][h][gg * 4 + 3][r]};
+                    *reinterpret_cast<f32x4*>(ob + ((int64_t)h * QC + 16 * nq + 4 * g + r) * VAL_DIM + 256 * wave + 64 * gg + 4 * j) = o;
+                }
             }
         }
-    }
-    z1 += __shfl_xor(z1, 16); z1 += __shfl_xor(z1, 32);
-    z2 += __shfl_xor(z2, 16); z2 += __shfl_xor(z2, 32);
-    if (wave == 0 && g == 0) {
-        a.zsum[((int64_t)blockIdx.x * 16 + j) * 2 + 0] = z1;
-        a.zsum[((int64_t)blockIdx.x * 16 + j) * 2 + 1] = z2;
+        float za = z1[nq], zb = z2[nq];
+        za += __shfl_xor(za, 16); za += __shfl_xor(za, 32);
+        zb += __shfl_xor(zb, 16); zb += __shfl_xor(zb, 32);
+        if (wave == 0 && g == 0) {
+            a.zsum[((int64_t)blockIdx.x * QC + 16 * nq + j) * 2 + 0] = za;
+            a.zsum[((int64_t)blockIdx.x * QC + 16 * nq + j) * 2 + 1] = zb;
+        }
     }
 }
 
@@ -252,8 +287,8 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 // ((1 - beta) * G + beta * H in float32) and packs with e-hat: out (B,1280) float64.
 // grid (B, 8): block y handles columns [128 y, 128 y + 128) as 32 float4; thread = (part 0..7, column).
 __global__ __launch_bounds__(256) void small_finalize_kernel(const float* __restrict__ osum, const float* __restrict__ zsum,
-                                                             int n_wg, int geo, float beta, const double* __restrict__ ehat64,
-                                                             double* __restrict__ out) {
+                                                             int n_wg, int qcap, int geo, float beta,
+                                                             const double* __restrict__ ehat64, double* __restrict__ out) {
     __shared__ f32x4 sh_o[2][8][32];
     __shared__ float sh_z[2][256];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -262,16 +297,16 @@ __global__ __launch_bounds__(256) void small_finalize_kernel(const float* __rest
     const int w0 = part * per, w1 = min(n_wg, w0 + per);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (int w = w0; w < w1; ++w) {
-        const float* ob = osum + (int64_t)w * (2 * 16 * VAL_DIM) + (int64_t)q * VAL_DIM + 4 * c4;
+        const float* ob = osum + (int64_t)w * (2 * qcap * VAL_DIM) + (int64_t)q * VAL_DIM + 4 * c4;
         s1 += *reinterpret_cast<const f32x4*>(ob);
-        if (geo) s2 += *reinterpret_cast<const f32x4*>(ob + 16 * VAL_DIM);
+        if (geo) s2 += *reinterpret_cast<const f32x4*>(ob + (int64_t)qcap * VAL_DIM);
     }
     sh_o[0][part][tid & 31] = s1;
     sh_o[1][part][tid & 31] = s2;
     // the weight sums: 256 values per head (zero beyond n_wg), a fixed tree
     {
         float za = 0.f, zb = 0.f;
-        for (int w = tid; w < n_wg; w += 256) { za += zsum[((int64_t)w * 16 + q) * 2]; zb += zsum[((int64_t)w * 16 + q) * 2 + 1]; }
+        for (int w = tid; w < n_wg; w += 256) { za += zsum[((int64_t)w * qcap + q) * 2]; zb += zsum[((int64_t)w * qcap + q) * 2 + 1]; }
         sh_z[0][tid] = za;
         sh_z[1][tid] = zb;
     }

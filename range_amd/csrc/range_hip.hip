@@ -91,7 +91,7 @@ struct range_ctx {
     bool topks_fused = true;                 // RANGE_TOPKS_FUSED=0: the merge as a second launch at every batch size (A/B)
     DevBuf<uint32_t> ws_topk_sync;           // TOPKS_SYNC_WORDS: arrival counters, done, sticky error, key-norm scratch
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
-    bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 16 queries take the two-pass kernels too (A/B)
+    bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 32 queries take the two-pass kernels too (A/B)
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
@@ -1303,7 +1303,7 @@ int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const d
     return RANGE_OK;
 }
 
-// Up to 16 queries: the whole retrieval in ONE pass over the bank (attend_small.h) - every CU
+// Up to 32 queries: the whole retrieval in ONE pass over the bank (attend_small.h) - every CU
 // streams its share of keys, locations and values once and accumulates the un-normalised products
 // of both heads; small_finalize_kernel sums the workgroups' partials, normalises, blends and packs.
 // e-hat / xq of the B queries are in the context's workspace (range_encode ran on `stream`).
@@ -1316,8 +1316,9 @@ static int forward_small(range_ctx* c, int64_t B, float tau_sem, float tau_geo, 
     const double LOG2E = 1.4426950408889634;
     const int n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
     const int n_wg = std::max(1, std::min(c->n_cu, n_blocks));
-    HIP_TRY(c->ws_small_o.ensure((size_t)n_wg * 2 * 16 * VAL_DIM));
-    HIP_TRY(c->ws_small_z.ensure((size_t)n_wg * 16 * 2));
+    const int nq = B > 16 ? 2 : 1, qcap = 16 * nq;            // query tiles of a workgroup
+    HIP_TRY(c->ws_small_o.ensure((size_t)n_wg * 2 * qcap * VAL_DIM));
+    HIP_TRY(c->ws_small_z.ensure((size_t)n_wg * qcap * 2));
     SmallArgs a{};
     a.keys = c->d_keys.p;
     a.xyz4 = c->d_xyz4.p;
@@ -1334,19 +1335,21 @@ static int forward_small(range_ctx* c, int64_t B, float tau_sem, float tau_geo, 
     const bool geo = tau_geo > 0.f;
     {
         ProfScope ps(c, RANGE_PROF_ATTEND, s);
-        if (geo) {
-            rc = set_dyn_lds(attend_small_kernel<true>, AS_LDS_BYTES);
-            if (rc) return rc;
-            hipLaunchKernelGGL(attend_small_kernel<true>, dim3((unsigned)n_wg), dim3(256), AS_LDS_BYTES, s, a);
-        } else {
-            rc = set_dyn_lds(attend_small_kernel<false>, AS_LDS_BYTES);
-            if (rc) return rc;
-            hipLaunchKernelGGL(attend_small_kernel<false>, dim3((unsigned)n_wg), dim3(256), AS_LDS_BYTES, s, a);
-        }
+#define RANGE_SMALL_LAUNCH(G, Q)                                                                   \
+    do {                                                                                           \
+        rc = set_dyn_lds(attend_small_kernel<G, Q>, as_lds_bytes(Q));                              \
+        if (rc) return rc;                                                                         \
+        hipLaunchKernelGGL((attend_small_kernel<G, Q>), dim3((unsigned)n_wg), dim3(256), as_lds_bytes(Q), s, a); \
+    } while (0)
+        if (geo && nq == 2) RANGE_SMALL_LAUNCH(true, 2);
+        else if (geo) RANGE_SMALL_LAUNCH(true, 1);
+        else if (nq == 2) RANGE_SMALL_LAUNCH(false, 2);
+        else RANGE_SMALL_LAUNCH(false, 1);
+#undef RANGE_SMALL_LAUNCH
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(small_finalize_kernel, dim3((unsigned)B, 8), dim3(256), 0, s, c->ws_small_o.p, c->ws_small_z.p,
-                       n_wg, geo ? 1 : 0, geo ? beta : 1.0f, c->ws_ehat64.p, out);
+                       n_wg, qcap, geo ? 1 : 0, geo ? beta : 1.0f, c->ws_ehat64.p, out);
     HIP_TRY(hipGetLastError());
     c->last_qtiles = 1;
     c->last_splits = n_wg;
@@ -1398,7 +1401,7 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
     if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
         return fail(RANGE_ERR_INVALID, "unknown model %d", model);
-    if (B > 0 && B <= 16 && c->small_forward) {
+    if (B > 0 && B <= 32 && c->small_forward) {
         // a handful of queries: one pass over the bank (attend_small.h)
         int rc = encode_to_workspace(c, lonlat, B, stream);
         if (rc) return rc;
@@ -1456,7 +1459,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     const float bt = model == RANGE_MODEL_RANGE ? 1.0f : beta;
     int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
     if (rc) return rc;
-    if (B <= 16 && c->small_forward) {
+    if (B <= 32 && c->small_forward) {
         // a handful of queries: one pass over the bank, one small copy
         rc = forward_small(c, B, tau_sem, tau_geo, bt, c->ws_out64.p, s);
         if (rc) return rc;

@@ -314,11 +314,11 @@ def test_encoder_wide_hidden_layers(L, H, layers, mode, Bs):
 
 @pytest.mark.parametrize("N", [9, 1000, 20011])
 def test_small_batches_take_one_pass_over_the_bank(N, monkeypatch):
-    """Up to 16 queries run attend_small_kernel (every CU streams its share of keys, locations and
+    """Up to 32 queries run attend_small_kernel (one or two tiles of 16 queries per workgroup; every CU streams its share of keys, locations and
     values ONCE and accumulates the un-normalised products of both heads) + small_finalize_kernel:
     against the float64 oracle and the reference's float32 op order, RANGE and RANGE+, several beta,
     banks that do not fill a 16-row block or have fewer blocks than CUs; the two-pass kernels
-    (RANGE_SMALL_FORWARD=0) agree to float32 rounding; 17 queries take the two-pass route."""
+    (RANGE_SMALL_FORWARD=0) agree to float32 rounding; 33 queries take the two-pass route."""
     L, H = 10, 64
     w, ws, bs = _weights(L, H, 2, 5)
     locs, vals, keys = synth.make_bank(N, 3)
@@ -333,14 +333,14 @@ def test_small_batches_take_one_pass_over_the_bank(N, monkeypatch):
     for e in (eng, two):
         e.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
         e.set_bank(bank.keys, bank.values, bank.xyz)
-    for B in (1, 5, 16, 17):
+    for B in (1, 5, 16, 17, 29, 32, 33):
         q = synth.make_queries(B, seed=N + B, lat_max=80.0)
         x = torch.from_numpy(q).cuda()
         for model, name, beta in ((_native.MODEL_RANGE_PLUS, "RANGE+", 0.5), (_native.MODEL_RANGE_PLUS, "RANGE+", 0.0),
                                   (_native.MODEL_RANGE_PLUS, "RANGE+", 1.0), (_native.MODEL_RANGE, "RANGE", 1.0)):
             eng.profile_enable(True)
             out = eng.forward(x, model, beta).cpu().numpy()
-            assert eng.profile_read(_native.PROF_SCAN_STATS)[1] == (0 if B <= 16 else 1)   # which route ran: no pass 1
+            assert eng.profile_read(_native.PROF_SCAN_STATS)[1] == (0 if B <= 32 else 1)   # which route ran: no pass 1
             eng.profile_enable(False)
             ref64 = O.retrieve64(out[:, 1024:], q, obank, name, beta)
             np.testing.assert_allclose(out[:, :1024], ref64, rtol=0, atol=2e-5)

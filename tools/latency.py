@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Forward latency of RANGE+ for small batches on the bench workload (GPU only): device-resident
 queries in, device-resident embeddings out, mean of 50 calls after warm-up, and the kernels' own
-times (HIP events per kernel).  Up to 16 queries run the one-pass kernel (attend_small.h;
+times (HIP events per kernel).  Up to 32 queries run the one-pass kernel (attend_small.h;
 RANGE_SMALL_FORWARD=0 sends them through the two-pass kernels for comparison)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ eng = _native.HipEngine(dev)
 eng.set_encoder(40, 512, 2, 256, 0, [w["layers.0.weight"], w["layers.1.weight"], w["last_layer.weight"]],
                 [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]], sh_table=sh_table.generate_table(40))
 eng.set_bank(bank.keys, bank.values, bank.xyz)
-for B in (1, 8, 16, 17, 32, 64, 256, 1024, 4096):
+for B in (1, 8, 16, 17, 32, 33, 64, 256, 1024, 4096):
     x = torch.from_numpy(synth.make_queries(B, seed=B)).to(dev)
     out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
     for _ in range(5):
