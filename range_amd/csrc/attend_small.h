@@ -282,43 +282,58 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
     }
 }
 
-// Sums the workgroups' partials (fixed order: 8 groups of consecutive workgroups, each summed in
-// order, then the 8 group sums in order), normalises, blends like range/range.py:238
+// Sums the workgroups' partials (fixed order: 32 groups of consecutive workgroups, each summed in
+// order, then the 32 group sums in order), normalises, blends like range/range.py:238
 // ((1 - beta) * G + beta * H in float32) and packs with e-hat: out (B,1280) float64.
-// grid (B, 8): block y handles columns [128 y, 128 y + 128) as 32 float4; thread = (part 0..7, column).
-__global__ __launch_bounds__(256) void small_finalize_kernel(const float* __restrict__ osum, const float* __restrict__ zsum,
-                                                             int n_wg, int qcap, int geo, float beta,
-                                                             const double* __restrict__ ehat64, double* __restrict__ out) {
-    __shared__ f32x4 sh_o[2][8][32];
-    __shared__ float sh_z[2][256];
+// grid (B, 8), 1024 threads: block y handles columns [128 y, 128 y + 128) as 32 float4; thread =
+// (part 0..31, column): 8 workgroups' partials per thread, their loads in flight together (with 8
+// parts of 32 the kernel took 13 us of dependent-latency loads for 33 MB).
+constexpr int SF_PARTS = 32;
+__global__ __launch_bounds__(1024) void small_finalize_kernel(const float* __restrict__ osum, const float* __restrict__ zsum,
+                                                              int n_wg, int qcap, int geo, float beta,
+                                                              const double* __restrict__ ehat64, double* __restrict__ out) {
+    __shared__ f32x4 sh_o[2][SF_PARTS][32];
+    __shared__ float sh_z[2][1024];
     const int q = blockIdx.x, tid = threadIdx.x;
     const int part = tid >> 5, c4 = blockIdx.y * 32 + (tid & 31);
-    const int per = (n_wg + 7) / 8;
+    const int per = (n_wg + SF_PARTS - 1) / SF_PARTS;
     const int w0 = part * per, w1 = min(n_wg, w0 + per);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (int w = w0; w < w1; ++w) {
-        const float* ob = osum + (int64_t)w * (2 * qcap * VAL_DIM) + (int64_t)q * VAL_DIM + 4 * c4;
+    const float* ob = osum + (int64_t)w0 * (2 * qcap * VAL_DIM) + (int64_t)q * VAL_DIM + 4 * c4;
+    const int64_t wstride = (int64_t)2 * qcap * VAL_DIM;
+    int w = w0;
+    for (; w + 8 <= w1; w += 8, ob += 8 * wstride) {
+        f32x4 t1[8], t2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            t1[i] = *reinterpret_cast<const f32x4*>(ob + i * wstride);
+            t2[i] = geo ? *reinterpret_cast<const f32x4*>(ob + i * wstride + (int64_t)qcap * VAL_DIM) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += t1[i]; s2 += t2[i]; }
+    }
+    for (; w < w1; ++w, ob += wstride) {
         s1 += *reinterpret_cast<const f32x4*>(ob);
         if (geo) s2 += *reinterpret_cast<const f32x4*>(ob + (int64_t)qcap * VAL_DIM);
     }
     sh_o[0][part][tid & 31] = s1;
     sh_o[1][part][tid & 31] = s2;
-    // the weight sums: 256 values per head (zero beyond n_wg), a fixed tree
+    // the weight sums: 1024 values per head (zero beyond n_wg), a fixed tree
     {
         float za = 0.f, zb = 0.f;
-        for (int w = tid; w < n_wg; w += 256) { za += zsum[((int64_t)w * qcap + q) * 2]; zb += zsum[((int64_t)w * qcap + q) * 2 + 1]; }
+        for (int ww = tid; ww < n_wg; ww += 1024) { za += zsum[((int64_t)ww * qcap + q) * 2]; zb += zsum[((int64_t)ww * qcap + q) * 2 + 1]; }
         sh_z[0][tid] = za;
         sh_z[1][tid] = zb;
     }
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
+    for (int d = 512; d >= 1; d >>= 1) {
         if (tid < d) { sh_z[0][tid] += sh_z[0][tid + d]; sh_z[1][tid] += sh_z[1][tid + d]; }
         __syncthreads();
     }
     if (part == 0) {
         f32x4 h = sh_o[0][0][tid], gsum = sh_o[1][0][tid];
 #pragma unroll
-        for (int p = 1; p < 8; ++p) { h += sh_o[0][p][tid]; gsum += sh_o[1][p][tid]; }
+        for (int p = 1; p < SF_PARTS; ++p) { h += sh_o[0][p][tid]; gsum += sh_o[1][p][tid]; }
         const float zh = sh_z[0][0], zg = sh_z[1][0];
         double* o = out + (int64_t)q * 1280 + 4 * c4;
 #pragma unroll
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(256) void small_finalize_kernel(const float* __rest
             o[e] = (double)m;
         }
     }
-    if (blockIdx.y == 0) out[(int64_t)q * 1280 + 1024 + tid] = ehat64[(int64_t)q * 256 + tid];
+    if (blockIdx.y == 0 && tid < 256) out[(int64_t)q * 1280 + 1024 + tid] = ehat64[(int64_t)q * 256 + tid];
 }
 
 }  // namespace range_hip

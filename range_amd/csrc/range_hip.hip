@@ -1348,7 +1348,7 @@ static int forward_small(range_ctx* c, int64_t B, float tau_sem, float tau_geo, 
 #undef RANGE_SMALL_LAUNCH
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(small_finalize_kernel, dim3((unsigned)B, 8), dim3(256), 0, s, c->ws_small_o.p, c->ws_small_z.p,
+    hipLaunchKernelGGL(small_finalize_kernel, dim3((unsigned)B, 8), dim3(1024), 0, s, c->ws_small_o.p, c->ws_small_z.p,
                        n_wg, qcap, geo ? 1 : 0, geo ? beta : 1.0f, c->ws_ehat64.p, out);
     HIP_TRY(hipGetLastError());
     c->last_qtiles = 1;
