@@ -1475,18 +1475,20 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
 
     // Pass 2 runs in a few launches over consecutive query ranges (boundaries on query tiles): the
     // device->host copy and the host fill of a part overlap pass 2 of the next, so only the LAST
-    // part's copy and fill are exposed - and the parts SHRINK: the rest, 4 096, 1 024 queries.  The
-    // copy pipeline (DMA 0.2 ms, host fill 0.35 ms per 1 000 queries) is four times faster than pass 2
-    // (1.46 ms per 1 000 queries against range_db_large), so a part four times the size of its
-    // successor is drained while the successor computes; the last 1 024 queries leave ~0.3 ms
-    // exposed (two equal halves left 1.4 ms).  Part sizes matter on the GPU side: the split count of
-    // pass 2 is chosen per launch so that its workgroups fill whole rounds of the chip, and 16 query
-    // tiles x 16 bank splits are exactly one round - measured for 10 000 queries (tools/host_parts.py,
-    // pass 2 in one launch 14.65 ms): parts (4 096, 1 024) 14.80 ms, (1 024) 14.85, (2 048, 512) 15.42.
+    // part's copy and fill are exposed - and the parts SHRINK: the rest, 4 096, 512 queries.  What
+    // bounds the end is the copy queue (RANGE_HOST_TIMING=1 prints when each slab's copy was seen):
+    // 0.205 ms per 1 000 queries (10 KB each at 52 GB/s) against 1.46 ms of pass 2 per 1 000 queries
+    // against range_db_large, so a part up to seven times its successor is drained while the
+    // successor computes; with (4 096, 1 024) the last slab was seen 0.35 ms after pass 2 ended, with
+    // (4 096, 512) 0.15 ms (two equal halves: 1.4 ms).  Part sizes matter on the GPU side too: the
+    // split count of pass 2 is chosen per launch so that its workgroups fill whole rounds of the
+    // chip (8 query tiles x 32 bank splits, 64 x 4: exactly one round) - measured for 10 000 queries,
+    // medians of 30 calls (tools/host_parts.py; the box wanders by +-0.1 ms): (4 096, 512) 19.71 ms,
+    // (2 048, 256) 19.70, (3 072, 512) 19.87, (4 096, 1 024) 19.96, (1 792, 256) 19.98.
     std::vector<int64_t> cuts{0};
     if (B >= 4096) {
         // RANGE_HOST_PARTS="2048,512": sizes of the parts behind the first (tuning)
-        std::vector<int64_t> tail{4096, 1024};
+        std::vector<int64_t> tail{4096, 512};
         if (const char* e = std::getenv("RANGE_HOST_PARTS")) {
             tail.clear();
             for (const char* q = e; *q;) {
@@ -1501,7 +1503,8 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         for (auto v : tail) rest += v;
         if (rest < B) {
             int64_t at = B - rest;
-            for (auto v : tail) { cuts.push_back(at / QTILE * QTILE); at += v; }
+            // (cuts rounded UP to a query tile: the last part is at most its nominal size, whole slabs)
+            for (auto v : tail) { cuts.push_back((at + QTILE - 1) / QTILE * QTILE); at += v; }
         }
     }
     cuts.push_back(B);
@@ -1554,6 +1557,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     }
     const auto t_enq = std::chrono::steady_clock::now();
     double wait_s = 0.0, copy_s = 0.0;
+    std::vector<double> landed;                 // (host_timing) when each slab's copy was seen, ms after entry
     for (auto& sl : slabs) {
         if (e != hipSuccess) break;
         const auto w0 = std::chrono::steady_clock::now();
@@ -1565,6 +1569,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         const auto w2 = std::chrono::steady_clock::now();
         wait_s += std::chrono::duration<double>(w1 - w0).count();
         copy_s += std::chrono::duration<double>(w2 - w1).count();
+        if (c->host_timing) landed.push_back(std::chrono::duration<double>(w1 - t_begin).count() * 1e3);
     }
     if (e != hipSuccess) {
         (void)hipDeviceSynchronize();
@@ -1577,6 +1582,11 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
                      "(%d threads), total %.2f ms\n", (long long)B,
                      std::chrono::duration<double>(t_enq - t_begin).count() * 1e3, wait_s * 1e3, copy_s * 1e3,
                      c->pool->size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
+    if (c->host_timing) {
+        std::fprintf(stderr, "  slab copies seen at (ms):");
+        for (size_t i = 0; i < landed.size(); ++i) std::fprintf(stderr, " %.2f(%lld)", landed[i], (long long)slabs[i].nq);
+        std::fprintf(stderr, "\n");
+    }
     return RANGE_OK;
 }
 

@@ -17,6 +17,10 @@ x = torch.from_numpy(synth.make_queries(10_000, seed=7, lat_max=90.0)).to(dev)
 for name, fn in (("forward (device result)", lambda: eng.forward(x, 1, 0.5)), ("forward_host", lambda: eng.forward_host(x, 1, 0.5))):
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    per = []
+    for _ in range(30):                      # per-call times: the box's clocks wander by +-0.2 ms
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); per.append(time.perf_counter() - t0)
+    per.sort()
     eng.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(10): fn()
@@ -24,4 +28,4 @@ for name, fn in (("forward (device result)", lambda: eng.forward(x, 1, 0.5)), ("
     dt = (time.perf_counter() - t0) / 10
     a, n = eng.profile_read(_native.PROF_ATTEND); s, _ = eng.profile_read(_native.PROF_SCAN_STATS); e, _ = eng.profile_read(_native.PROF_ENCODER)
     eng.profile_enable(False)
-    print(f"{name}: {dt*1e3:.2f} ms per call; pass 2 {a/10:.2f} ms in {n//10} launches, pass 1 {s/10:.2f}, encoder {e/10:.2f}")
+    print(f"{name}: {dt*1e3:.2f} ms per call (of 30 single calls: median {per[15]*1e3:.2f}, fastest quarter {per[7]*1e3:.2f}); pass 2 {a/10:.2f} ms in {n//10} launches, pass 1 {s/10:.2f}, encoder {e/10:.2f}")
