@@ -150,6 +150,36 @@ def test_c3_range_db_large_100k_queries(tmp_path):
         m.engine.set_pv_mode("exact")
 
 
+def test_small_batches_at_full_size(tmp_path):
+    """The latency path at the benchmark's sizes (range_db_large, L = 40, H = 512): 1 / 16 / 17 / 32
+    queries run the persistent encoder launch and ONE pass over the bank (attend_small.h, one or two
+    query tiles per workgroup), 33 and 512 queries the persistent encoder and the two-pass kernels.
+    Every row against the float64 oracle and the reference's float32 order, against the same rows of
+    one large batch (other kernels, other summation orders: float32 rounding), bit-identical when
+    repeated, and the numpy contract returns the same bits."""
+    N = synth.BANK_ROWS["range_db_large"]
+    m, obank, w = _model(tmp_path, N)
+    q = synth.make_queries(1024, seed=11)
+    x = torch.from_numpy(q).to("cuda:0")
+    big = m(x, return_device=True).cpu().numpy()
+    for B in (1, 16, 17, 32, 33, 512):
+        m.engine.profile_enable(True)
+        out = m(x[:B], return_device=True)
+        one_pass = m.engine.profile_read(1)[1] == 0          # no pass 1 ran
+        m.engine.profile_enable(False)
+        assert one_pass == (B <= 32)
+        for _ in range(3):
+            assert torch.equal(m(x[:B], return_device=True), out)
+        got = out.cpu().numpy()
+        e = got[:, 1024:]
+        np.testing.assert_allclose(e, big[:B, 1024:], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(got[:, :1024], O.retrieve64(e, q[:B], obank, "RANGE+", 0.5), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(got, O.retrieve(e, q[:B], obank, "RANGE+", 0.5), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(got[:, :1024], big[:B, :1024], rtol=0, atol=1e-5)
+        assert np.abs(got[:, 0] - 1.0).max() < 1e-5 and np.abs(got[:, 1] + 2.5).max() < 2.5e-5
+        assert np.array_equal(m(x[:B]), got)
+
+
 def test_bench_self_launches_two_ranks():
     """``python bench.py --gpus 2`` from a plain shell starts its own rank processes (fresh
     children, torch.distributed.run) and relays rank 0's line.  Two gloo ranks share the one GPU
