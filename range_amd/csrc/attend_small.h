@@ -168,18 +168,43 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
         asm volatile("" : "+v"(xa));
         issue_kx(t + 2);                                   // (the slots just read are free: wave-private)
         f32x4 c[NQ], cg[NQ];
+        if (NQ * (GEO ? 2 : 1) > 2) {
+            // every accumulator register is taken by the products (256, pinned below): the logit
+            // tiles are formed in VECTOR registers by the asm forms - with the builtin hipcc parked
+            // four accumulator tiles in vector registers around this chain, reading the results of
+            // MFMAs it does not know to be MFMAs without their wait states (checked on the
+            // generated code: tests/test_host_cpu.py)
 #pragma unroll
-        for (int nq = 0; nq < NQ; ++nq) {
-            c[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nq = 0; nq < NQ; ++nq) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[nq][s].x, c[nq], 0, 0, 0);
-                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[nq][s].y, c[nq], 0, 0, 0);
-                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[nq][s].z, c[nq], 0, 0, 0);
-                c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[nq][s].w, c[nq], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    if (s == 0) mfma_v_first(c[nq], kf[s].x, qf[nq][s].x);
+                    else mfma_v(c[nq], kf[s].x, qf[nq][s].x);
+                    mfma_v(c[nq], kf[s].y, qf[nq][s].y);
+                    mfma_v(c[nq], kf[s].z, qf[nq][s].z);
+                    mfma_v(c[nq], kf[s].w, qf[nq][s].w);
+                }
+                if (GEO) mfma_v_first(cg[nq], xa, xqv[nq]);
+                else cg[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            cg[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (GEO) cg[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xqv[nq], cg[nq], 0, 0, 0);
+            // (the tiles are read by ordinary instructions next: an 8-pass MFMA result needs 11 wait
+            // states before that, which hipcc cannot know about - 16 here, like QKAcc::fence)
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) asm volatile("s_nop 15" : "+v"(c[nq]), "+v"(cg[nq]));
+        } else {
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) {
+                c[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[nq][s].x, c[nq], 0, 0, 0);
+                    c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[nq][s].y, c[nq], 0, 0, 0);
+                    c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[nq][s].z, c[nq], 0, 0, 0);
+                    c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[nq][s].w, c[nq], 0, 0, 0);
+                }
+                cg[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (GEO) cg[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xqv[nq], cg[nq], 0, 0, 0);
+            }
         }
         // ---- the four k-slices meet: partial tiles through LDS, summed in a fixed order
         f32x4* xb = xbuf + (t & 1) * (NQ * 256);

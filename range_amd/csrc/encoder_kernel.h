@@ -693,8 +693,13 @@ __global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
 // written through (st_xwg), every storing wave waits vmcnt(0), workgroup barrier, ONE lane of the
 // workgroup increments the phase's counter; a consuming workgroup polls it (sc1 load) and reads
 // the buffers with sc1 loads (ld_xwg) behind a barrier that lane joins.  All workgroups are
-// resident (grid <= CUs, one per CU) and arrive before they wait.  The counters wrap to zero by
-// themselves: arrivals + one increment per consumer = the wrap limit of the atomic inc.
+// resident (grid <= CUs, one per CU) and arrive before they wait.  If CUs are held by someone
+// else's kernels (another process on the same GPU) the launch is only slower, never stuck:
+// workgroups are dispatched in blockIdx order, the producers of phase 1 never wait and leave when
+// done, and from phase 2 on producers and consumers are the same K workgroups, resident by then;
+// a wait that does not end within ENC_SPIN_LIMIT polls (seconds) gives up instead of hanging.
+// The counters wrap to zero by themselves: arrivals + one increment per consumer = the wrap limit
+// of the atomic inc.
 constexpr uint32_t ENC_SPIN_LIMIT = 1u << 21;
 // returns false for a workgroup that has no part in the next phase (or whose wait gave up)
 __device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag) {

@@ -171,6 +171,35 @@ def test_no_foreign_m0_writes(tmp_path):
         assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", k), f"{name} uses scratch memory"
         assert not re.search(r"\n\s*flat_(load|store|atomic)", k), f"{name}: flat memory access"
     assert n_stream == 4
+    # fourth check: the one-pass kernels (attend_small.h).  Where MFMAs are inline asm (two query
+    # tiles, both heads: 256 pinned accumulator registers) hipcc does not know their results need
+    # wait states: nothing but the asm MFMAs themselves may touch their destination registers inside
+    # the loop (a first build parked accumulator tiles in vector registers around the logit chain);
+    # and a spill inside the loop would be a vector-memory operation among the hand-counted ones
+    n_small = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if "attend_small_kernel" not in name:
+            continue
+        n_small += 1
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", k), f"{name} uses scratch memory"
+        body = [l.split(";")[0].strip() for l in k.splitlines()]
+        body = [l for l in body if l and not l.startswith(".") and not l.startswith("#")]
+        asm_dst = set()
+        for i, l in enumerate(body[:-1]):
+            m = re.match(r"v_mfma\S+ ([av])\[(\d+):(\d+)\]", l)
+            if m and body[i + 1] == "s_nop 1":                     # (the asm forms carry a trailing s_nop 1)
+                asm_dst.update((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+        for l in body:
+            if l.startswith("v_accvgpr") and "a[" not in l:
+                regs = {("a", int(x)) for x in re.findall(r"\ba(\d+)\b", l)}
+                # (zero-initialisation in front of the loop and the read-out behind it are apart from
+                # every MFMA by construction: writes of 0 / reads after the final vmcnt(0) wait)
+                if regs & asm_dst and "v_accvgpr_read" in l:
+                    idx = body.index(l)
+                    last_mfma = max(i for i, b in enumerate(body) if b.startswith("v_mfma"))
+                    assert idx > last_mfma, f"{name}: accumulator of an asm MFMA read inside the loop: {l}"
+    assert n_small == 4
 
 
 def test_bankfile_roundtrip_and_shards(tmp_path):
