@@ -24,8 +24,12 @@
 //     hand-counted vmcnt waits: its 256-byte slice of the key rows (2 slots), its 1 KB slice of the
 //     value rows in 8-row halves (3 slots), the 16 locations.  Nothing else crosses waves, so the
 //     rings need no barrier; ~20 KB per wave (80 KB per CU) are in flight all the time.
-//   * MFMAs are compiler builtins (v_mfma_f32_16x16x4_f32: exact float32 products): the kernel is
-//     HBM-bound (145 MFMAs per block and wave = 4.6 k cycles against 80 KB of bank at ~25 B/clk/CU).
+//   * MFMAs are v_mfma_f32_16x16x4_f32 (exact float32 products), compiler builtins where hipcc can
+//     be left to place them.  What bounds the kernel (stamps, round 3: profiles/NOTES.md A.2): not
+//     HBM - a wave waits 1 us for memory in a loop of 80 - but, per 16-row block, 145 MFMAs at 30.5
+//     cycles plus ~3 000 cycles in which the matrix cores wait for the chain LDS read -> logits ->
+//     exchange -> exp2 with one wave per SIMD.  5.2 TB/s is what that leaves; the loop as a fixed
+//     asm schedule (as pass 2 has it) is the open item.
 //
 // Logit tile transposed (bank row on the MFMA row index, query on the lane) with the row
 // permutation pi_row, as everywhere: accumulator registers 0,1 of the logit tile are rows of the
