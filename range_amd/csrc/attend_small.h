@@ -25,11 +25,17 @@
 //     value rows in 8-row halves (3 slots), the 16 locations.  Nothing else crosses waves, so the
 //     rings need no barrier; ~20 KB per wave (80 KB per CU) are in flight all the time.
 //   * MFMAs are v_mfma_f32_16x16x4_f32 (exact float32 products), compiler builtins where hipcc can
-//     be left to place them.  What bounds the kernel (stamps, round 3: profiles/NOTES.md A.2): not
-//     HBM - a wave waits 1 us for memory in a loop of 80 - but, per 16-row block, 145 MFMAs at 30.5
-//     cycles plus ~3 000 cycles in which the matrix cores wait for the chain LDS read -> logits ->
-//     exchange -> exp2 with one wave per SIMD.  5.2 TB/s is what that leaves; the loop as a fixed
-//     asm schedule (as pass 2 has it) is the open item.
+//     be left to place them.  What bounds the kernel (round 3, profiles/NOTES.md A.2): the 16-query
+//     loop streams its 513 MB in 80 us = 6.4 TB/s, the rate a plain copy reaches on this chip - it
+//     is HBM-bound, and timing builds without the exchange, without the logit MFMAs, without the
+//     LDS reads of V (-DRANGE_EXP_AS_NOEXCH / _NOLOGITS / _NOVREAD, results invalid) take the same
+//     time to the microsecond.  The waves do not wait in their vmcnt waits (1 us of 80) but at the
+//     ISSUE of the next LDS-DMA request, which blocks while the memory pipeline is full - stamps
+//     around the waits alone read as "compute-bound".  The rest of the kernel's 93-99 us: ~6 us
+//     before the first data, ~5 us to write the 33 MB of partials, the spread of the workgroups'
+//     ends.  With two query tiles (290 MFMAs per block and wave: 100 us of matrix-core time against
+//     80 us of bank) the two do not overlap perfectly - an MFMA behind a blocked request waits
+//     with it: 131 us.
 //
 // Logit tile transposed (bank row on the MFMA row index, query on the lane) with the row
 // permutation pi_row, as everywhere: accumulator registers 0,1 of the logit tile are rows of the
@@ -199,6 +205,9 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 #pragma unroll
             for (int nq = 0; nq < NQ; ++nq) {
                 c[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef RANGE_EXP_AS_NOLOGITS
+                c[nq] = kf[0] + kf[1] + kf[2] + kf[3];
+#else
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[nq][s].x, c[nq], 0, 0, 0);
@@ -206,24 +215,33 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
                     c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[nq][s].z, c[nq], 0, 0, 0);
                     c[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[nq][s].w, c[nq], 0, 0, 0);
                 }
+#endif
                 cg[nq] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (GEO) cg[nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xqv[nq], cg[nq], 0, 0, 0);
             }
         }
         // ---- the four k-slices meet: partial tiles through LDS, summed in a fixed order
         f32x4* xb = xbuf + (t & 1) * (NQ * 256);
+#ifndef RANGE_EXP_AS_NOEXCH      // (timing experiments: results invalid)
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) xb[(nq * 4 + wave) * 64 + lane] = c[nq];
+#ifndef RANGE_EXP_AS_NOBAR
         __syncthreads();
+#endif
+#endif
         // ---- un-normalised weights of both heads (pad rows of the bank's last block: 0)
         const uint32_t row0 = (uint32_t)(b0 + t) * BLK;
         float p1[NQ][4], p2[NQ][4];
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
+#ifdef RANGE_EXP_AS_NOEXCH
+            f32x4 sv = c[nq];
+#else
             f32x4 sv = xb[(nq * 4 + 0) * 64 + lane];
             sv += xb[(nq * 4 + 1) * 64 + lane];
             sv += xb[(nq * 4 + 2) * 64 + lane];
             sv += xb[(nq * 4 + 3) * 64 + lane];
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = row0 + prow[r] < (uint32_t)a.n_valid;
@@ -249,7 +267,11 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
+#ifdef RANGE_EXP_AS_NOVREAD
+                for (int gg = 0; gg < 4; ++gg) vb[rr][gg] = f32x4{(float)t, (float)h, (float)rr, (float)gg};
+#else
                 for (int gg = 0; gg < 4; ++gg) vb[rr][gg] = *reinterpret_cast<const f32x4*>(vt + rr * 1024 + gg * 256);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
