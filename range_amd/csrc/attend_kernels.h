@@ -235,6 +235,11 @@ __device__ __forceinline__ void dma_b128(const void* sbase, uint32_t voff, uint3
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                  :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
 }
+// (non-temporal cache policy: data streamed once per launch)
+__device__ __forceinline__ void dma_b128_nt(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt"
+                 :: "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+}
 // Group form: the instruction's immediate offset is applied to BOTH the global and the LDS
 // address, so a run of pieces that is contiguous in both spaces (the 4 quarter rows of a V row,
 // the 4 rows of a K tile) needs M0 and the SGPR base only once.  dma_group_begin sets M0;

@@ -69,6 +69,13 @@ constexpr int AS_WAVE_LDS = AS_OFF_X + 2 * AS_X_BYTES;     // 33 280 B per wave
 constexpr int AS_OFF_XBUF = 4 * AS_WAVE_LDS;               // partial logit tiles: 2 buffers x NQ x 4 waves x 1 KB
 constexpr int as_lds_bytes(int nq) { return AS_OFF_XBUF + 2 * nq * 4 * 1024; }
 
+// the bank is streamed once per launch: non-temporal requests (measured, 16 queries against
+// range_db_large: 99 -> 94 us per call; RANGE_EXP_AS_TEMPORAL restores the default policy)
+#ifdef RANGE_EXP_AS_TEMPORAL
+#define AS_DMA dma_b128
+#else
+#define AS_DMA dma_b128_nt
+#endif
 template <bool GEO, int NQ>
 __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
         const int slot = t & 1;
         const float* ksrc = a.keys + (int64_t)(b0 + tt) * BLK * KEY_DIM;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_b128(ksrc, kvoff[i], wl_lds + AS_OFF_K + slot * AS_K_BYTES + i * 1024);
+        for (int i = 0; i < 4; ++i) AS_DMA(ksrc, kvoff[i], wl_lds + AS_OFF_K + slot * AS_K_BYTES + i * 1024);
         if (GEO) dma_b32(a.xyz4 + (int64_t)(b0 + tt) * BLK * 4, (uint32_t)(lane << 2), wl_lds + AS_OFF_X + slot * AS_X_BYTES);
     };
     const uint32_t vvoff = (uint32_t)(wave * 1024 + (lane << 4));
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
         const uint32_t dst = wl_lds + (uint32_t)(v % AS_VSLOTS) * AS_V_BYTES;
         const float* vsrc = a.values + ((int64_t)(b0 + tt) * BLK + 8 * h) * VAL_DIM;
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) dma_b128(vsrc + r8 * VAL_DIM, vvoff, dst + r8 * 1024);
+        for (int r8 = 0; r8 < 8; ++r8) AS_DMA(vsrc + r8 * VAL_DIM, vvoff, dst + r8 * 1024);
     };
     constexpr int OPS_KX = GEO ? 5 : 4, OPS_V = 8;
     // the order of the steady state: [K X (t+2)] after the logits of t, [V (t+1, 1)] after the first
