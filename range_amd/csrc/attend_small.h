@@ -137,6 +137,21 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) AS_DMA(vsrc + r8 * VAL_DIM, vvoff, dst + r8 * 1024);
     };
+    // one row of the same request (RANGE_AS_SPREAD: the eight requests of a half go out between its
+    // MFMAs, one per 16, instead of in a burst in front of them - a burst into a full memory
+    // pipeline blocks the wave, and the matrix cores with it, until there is room for all eight)
+    auto issue_v_row = [&](int v, int r8) __attribute__((always_inline)) {
+        const int t = v >> 1, h = v & 1;
+        const int tt = t < nb ? t : nb - 1;
+        const uint32_t dst = wl_lds + (uint32_t)(v % AS_VSLOTS) * AS_V_BYTES;
+        const float* vsrc = a.values + ((int64_t)(b0 + tt) * BLK + 8 * h) * VAL_DIM;
+        AS_DMA(vsrc + r8 * VAL_DIM, vvoff, dst + r8 * 1024);
+    };
+#ifdef RANGE_EXP_AS_BURST
+    constexpr bool SPREAD = false;
+#else
+    constexpr bool SPREAD = NQ * (GEO ? 2 : 1) > 2;     // (the asm-MFMA kernel: program order is issue order)
+#endif
     constexpr int OPS_KX = GEO ? 5 : 4, OPS_V = 8;
     // the order of the steady state: [K X (t+2)] after the logits of t, [V (t+1, 1)] after the first
     // half of t, [V (t+2, 0)] after its second half
@@ -284,12 +299,13 @@ __global__ __launch_bounds__(256, 1) void attend_small_kernel(SmallArgs a) {
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) asm volatile("" : "+v"(vb[rr][gg]));
-            issue_v(2 * t + h + 3);                        // (into the slot just read)
+            if (!SPREAD) issue_v(2 * t + h + 3);           // (into the slot just read)
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int r = 2 * h + rr;
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
+                    if (SPREAD) issue_v_row(2 * t + h + 3, 4 * rr + gg);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
 #pragma unroll
