@@ -425,7 +425,14 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
         const f32x4 ss = {c.sem(0), c.sem(1), c.sem(2), c.sem(3)};
         const f32x4 sg = c.g;
         if (a.logits)   // keep the tile for pass 2 (the barrier's vmcnt(0) also covers this store)
+            // (non-temporal: 4 GB per 10^4 x 10^5 launch that nobody reads before pass 2 - measured
+            // three A/B pairs, 10 000 queries: pass 1 3.937 -> 3.916 ms, the pass 2 behind it 14.690 ->
+            // 14.616 ms; -DRANGE_EXP_P1_TSTORE restores the default policy)
+#ifdef RANGE_EXP_P1_TSTORE
             *reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
+#else
+            __builtin_nontemporal_store(ss, reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane));
+#endif
         // statistics of this tile.  Only the bank's last block can hold pad rows: every other
         // tile takes the unmasked form
         const int64_t row0 = (int64_t)(b0 + t) * BLK;
