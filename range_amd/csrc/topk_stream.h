@@ -83,6 +83,11 @@ struct TopkStreamArgs {
 #ifndef RANGE_TOPKS_VALU_PER_MFMA
 #define RANGE_TOPKS_VALU_PER_MFMA 4
 #endif
+#ifdef RANGE_EXP_TS_TEMPORAL
+#define TS_DMAQ dma_b128_q
+#else
+#define TS_DMAQ dma_b128_q_nt
+#endif
 constexpr int TOPKS_SG = 4;         // groups whose lists a wave carries through consecutive passes
 constexpr int TOPKS_WL = 8;         // entries of a wave's and of a workgroup's list of one query
 constexpr int TOPKS_RING_BYTES = 8 * BLK * KEY_DIM * 4;          // 128 KB of key tiles per workgroup
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void topk_stream_kernel(TopkStream
             for (int i4 = 0; i4 < 4; ++i4)
                 // (non-temporal: a key tile is read by exactly one wave per pass - measured 1 us
                 // per 16-query launch and 3 us per four passes faster than the default policy)
-                dma_b128_q_nt(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i4)) << 4), i4);
+                TS_DMAQ(src + gr * 4 * KEY_DIM, (uint32_t)((lane ^ (4 * gr + i4)) << 4), i4);
         }
     };
     // the first pass's query fragments first (topk_qwait below), the ring's first requests behind them
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream_bf16_kernel(TopkStreamArgs
         for (int gr = 0; gr < 2; ++gr) {
             dma_group_begin(dst + gr * 4096);
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) dma_b128_q_nt(src + gr * 4096, (uint32_t)(lane << 4), i4);
+            for (int i4 = 0; i4 < 4; ++i4) TS_DMAQ(src + gr * 4096, (uint32_t)(lane << 4), i4);
         }
     };
     // the first pass's query rows first (topk_qwait below), the ring's first requests behind them:
