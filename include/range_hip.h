@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 5
+#define RANGE_ABI_VERSION 6
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -129,7 +129,14 @@ int32_t range_get_pv_mode(const range_ctx* ctx);
  *   lonlat_dev : (B,2) float64, (lon,lat) degrees
  *   ehat64_dev : (B,256) float64   normalised embedding (output columns 1024:1280)
  *   ehat32_dev : (B,256) float32   the .float() operand of range.py:213
- *   xq32_dev   : (B,4)   float32   (x,y,z,0), the .float() operand of range.py:231 */
+ *   xq32_dev   : (B,4)   float32   (x,y,z,0), the .float() operand of range.py:231
+ * Up to 512 queries run as ONE persistent launch whose workgroups wait for each other inside the
+ * kernel (bounded: seconds).  Should such a wait ever give up - only when something else holds the
+ * GPU's CUs that long - the kernel sets a word of host-mapped memory; the NEXT encoder call on this
+ * context (and range_forward_host, which synchronises, before it returns) reports RANGE_ERR_HIP
+ * instead of handing out that call's wrong rows.  range_debug_raise_async_error sets the word the
+ * way the kernel would (test hook). */
+int range_debug_raise_async_error(range_ctx* ctx, range_stream_t stream);
 int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* ehat64_dev,
                  float* ehat32_dev, float* xq32_dev, range_stream_t stream);
 

@@ -36,7 +36,7 @@ SYMBOLS = (
     "range_attend_diag", "range_encode_raw", "range_blend", "range_topk_stream",
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
-    "range_set_pv_mode", "range_get_pv_mode", "range_set_keys",
+    "range_set_pv_mode", "range_get_pv_mode", "range_set_keys", "range_debug_raise_async_error",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -75,6 +75,7 @@ def load_library() -> C.CDLL:
     lib.range_set_sh_table.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.range_set_bank.argtypes = [vp, vp, vp, vp, i64, i64]
     lib.range_set_keys.argtypes = [vp, vp, i64, i64]
+    lib.range_debug_raise_async_error.argtypes = [vp, vp]
     lib.range_bank_rows.argtypes = [vp]
     lib.range_bank_rows.restype = i64
     lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -104,7 +105,7 @@ def load_library() -> C.CDLL:
     lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 5:
+    if lib.range_abi_version() != 6:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
     flags = lib.range_build_flags().decode()
     if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":

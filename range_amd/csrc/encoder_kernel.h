@@ -88,6 +88,7 @@ struct EncArgs {
     // encoder_tile_kernel (one 16-query tile, one launch): 4 arrival counters, 64 words apart; zero
     // when the context is created, left zero by every launch
     uint32_t* sync;
+    uint32_t* err;              // host-mapped word (or null): set when a bounded in-kernel wait gave up
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -702,7 +703,8 @@ __global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
 // of the atomic inc.
 constexpr uint32_t ENC_SPIN_LIMIT = 1u << 21;
 // returns false for a workgroup that has no part in the next phase (or whose wait gave up)
-__device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag) {
+__device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag,
+                                               uint32_t* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (every wave: its stores have completed)
     __syncthreads();
     if (threadIdx.x == 0) atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));
@@ -711,7 +713,13 @@ __device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_
         int ok = 1;
         for (uint32_t spins = 0;
              __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)n_prod; ++spins) {
-            if (spins > ENC_SPIN_LIMIT) { ok = 0; break; }
+            if (spins > ENC_SPIN_LIMIT) {
+                // the tile's later phases do not run: say so where the host sees it without a
+                // synchronisation (range_hip.hip: check_async_error)
+                if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));     // (the last consumer's increment wraps the counter to 0)
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // the second layer, but 4 the last one); the others leave after the first layer.
     const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
     const int K = max(max(n_act, a.n_parts2), 4);
-    if (!enc_phase_sync(sync, n_wg, K, b < K, flag)) return;
+    if (!enc_phase_sync(sync, n_wg, K, b < K, flag, a.err)) return;
     ENC_STAMP(2);
     if (b < n_act) {
         const int e = b * (int)blockDim.x + (int)threadIdx.x;
@@ -761,17 +769,17 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     }
     ENC_STAMP(3);
     // ---- second layer on the first n_parts2 workgroups
-    if (!enc_phase_sync(sync + 64, K, K, true, flag)) return;
+    if (!enc_phase_sync(sync + 64, K, K, true, flag, a.err)) return;
     ENC_STAMP(4);
     if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, q0, smem, b);
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
-    if (!enc_phase_sync(sync + 128, K, K, true, flag)) return;
+    if (!enc_phase_sync(sync + 128, K, K, true, flag, a.err)) return;
     ENC_STAMP(6);
     if (b < 4) encoder_body<4, 4, 1, 4>(a, q0, smem, b);
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
-    if (!enc_phase_sync(sync + 192, K, 1, b == 0, flag)) return;
+    if (!enc_phase_sync(sync + 192, K, 1, b == 0, flag, a.err)) return;
     {
         const int64_t q = q0 + (threadIdx.x >> 6);
         if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);

@@ -98,6 +98,10 @@ struct range_ctx {
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
     DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
     DevBuf<uint32_t> ws_enc_sync;   // encoder_tile_kernel: 4 phase counters, 64 words apart
+    // a word of host memory the kernels can write (hipHostMallocMapped): set by a persistent kernel
+    // whose bounded wait for other workgroups gave up; read - without synchronising - by the next call
+    uint32_t* h_async_err = nullptr;
+    uint32_t* d_async_err = nullptr;
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
     int last_qtiles = 0, last_splits = 0;
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
@@ -119,6 +123,7 @@ struct range_ctx {
     }
     ~range_ctx() {
         if (h_stage) (void)hipHostFree(h_stage);
+        if (h_async_err) (void)hipHostFree(h_async_err);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto& v : prof) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -185,6 +190,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         a.h1a = c->ws_h1a.p;
         a.e3 = c->ws_e3.p;
         a.sync = c->ws_enc_sync.p;
+        a.err = c->d_async_err;
         a.n_parts2 = a.H / 64;
         a.part2_cols = 64;
         a.rest_from = 1;
@@ -502,6 +508,21 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
     if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_SMALL_FORWARD")) c->small_forward = e[0] != '0';
+    {
+        DeviceGuard g(device);
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+            std::memset(hp, 0, 64);
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                c->h_async_err = (uint32_t*)hp;
+                c->d_async_err = (uint32_t*)dp;
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();       // (without the word the kernels simply do not report)
+    }
     *out = c;
     return RANGE_OK;
 }
@@ -715,14 +736,43 @@ int range_set_pv_mode(range_ctx* c, int32_t mode) {
 }
 int32_t range_get_pv_mode(const range_ctx* c) { return c ? c->pv_mode : -1; }
 
+// A persistent kernel of an EARLIER call that gave up waiting for its other workgroups (possible only
+// when something else holds the GPU's CUs for seconds) has left wrong results behind: the word it
+// set in host memory is read here, in front of the next encoder call and behind every synchronous
+// one, without touching the stream.
+static int check_async_error(range_ctx* c) {
+    if (c->h_async_err && *(volatile uint32_t*)c->h_async_err) {
+        *(volatile uint32_t*)c->h_async_err = 0;
+        return fail(RANGE_ERR_HIP, "a persistent encoder launch of an earlier call gave up waiting for its workgroups "
+                                   "(is another process holding the GPU?); the results of that call are invalid");
+    }
+    return RANGE_OK;
+}
+
+__global__ void raise_async_error_kernel(uint32_t* err) {
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// test hook: what a persistent kernel does when its bounded wait gives up (tests/test_gpu_round2.py)
+int range_debug_raise_async_error(range_ctx* c, range_stream_t stream) {
+    if (!c) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->d_async_err) return fail(RANGE_ERR_STATE, "no host-mapped error word in this context");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipLaunchKernelGGL(raise_async_error_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->d_async_err);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
 static int encode_impl(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
                        float* xq32, double* eraw64, range_stream_t stream) {
     if (!c || !lonlat || !ehat64 || !ehat32 || !xq32) return fail(RANGE_ERR_INVALID, "null argument");
     if (!c->has_encoder) return fail(RANGE_ERR_STATE, "encoder not set (range_set_encoder)");
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
+    if (int rc = check_async_error(c)) return rc;
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     EncArgs a = c->enc;
+    a.err = c->d_async_err;
     a.lonlat = lonlat;
     a.ehat64 = ehat64;
     a.eraw64 = eraw64;
@@ -1465,6 +1515,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_stage, c->ws_out64.p, (size_t)B * row_bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (int rc2 = check_async_error(c)) return rc2;
         std::memcpy(out_host, c->h_stage, (size_t)B * row_bytes);
         return RANGE_OK;
     }
@@ -1577,6 +1628,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         return fail(RANGE_ERR_HIP, "range_forward_host: %s", hipGetErrorString(e));
     }
     give_back();
+    if (int rc2 = check_async_error(c)) return rc2;
     if (c->host_timing)
         std::fprintf(stderr, "range_forward_host B=%lld: enqueue %.2f ms, waiting for slabs %.2f ms, host fill %.2f ms "
                      "(%d threads), total %.2f ms\n", (long long)B,

@@ -406,3 +406,29 @@ def test_one_tile_encoder_over_widths(L, H):
         e64, e32, xq = eng.encode(torch.from_numpy(q).cuda())
         np.testing.assert_allclose(e64.cpu().numpy(), O.encode(q, w, L, "closed-form"), rtol=0, atol=2e-12)
         np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1.2e-7)
+
+
+def test_a_given_up_in_kernel_wait_is_reported_by_the_next_call():
+    """The persistent encoder's waits between workgroups are bounded; one that gives up sets a word
+    of host-mapped memory (include/range_hip.h at range_encode).  The test hook sets the word the
+    way the kernel would: the next encoder call refuses with RANGE_ERR_HIP without touching the
+    stream, the numpy contract refuses before it hands out rows, and the context works again after."""
+    L, H = 10, 64
+    w, ws, bs = _weights(L, H, 2, 5)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    bank = prepare_bank(*synth.make_bank(500, 3))
+    eng.set_bank(bank.keys, bank.values, bank.xyz)
+    x = torch.from_numpy(synth.make_queries(16, seed=1)).cuda()
+    good = eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5).cpu().numpy()
+    _native._check(eng.lib, eng.lib.range_debug_raise_async_error(eng._h, eng._stream()))
+    torch.cuda.synchronize()
+    with pytest.raises(_native.RangeNativeError, match="gave up waiting"):
+        eng.encode(x)
+    assert np.array_equal(eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5).cpu().numpy(), good)   # reported once, then clear
+    # raised while a synchronous call is in flight: that call itself refuses
+    _native._check(eng.lib, eng.lib.range_debug_raise_async_error(eng._h, eng._stream()))
+    torch.cuda.synchronize()
+    with pytest.raises(_native.RangeNativeError, match="gave up waiting"):
+        eng.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5)
+    assert np.array_equal(eng.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5), good)
