@@ -10,7 +10,7 @@ for n in (100_000, 1_000_000):
     keys = make_keys(n, dev)
     eng = _native.HipEngine(dev); eng.set_keys(keys)
     g = torch.Generator().manual_seed(0)
-    for B in (16, 64):
+    for B in (16, 32, 64):
         e32 = torch.nn.functional.normalize(torch.randn(B, 256, generator=g), dim=1).cuda()
         os.environ.pop("RANGE_TOPKS_STAMPS", None)
         for _ in range(5): eng.topk_stream(e32, 16)
