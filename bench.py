@@ -279,7 +279,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(scaling, steps, warmup):
+    def measure(scaling, steps, warmup, eng=eng, model=model, sharded=sharded):
         """One timed leg.  Returns a dict of raw measurements (rank-local except dt = max over ranks)."""
         if scaling == "strong":
             if a.queries % world:
@@ -341,11 +341,17 @@ def main():
                                                     ("scan_stats", _native.PROF_SCAN_STATS),
                                                     ("encoder", _native.PROF_ENCODER))}
         eng.profile_enable(False)
-        comm_ms = model.comm_timing(False) if model is not None else None
+        comm_ms = model.comm_timing(False) if model is not None else None     # per kind of collective + "total"
         assert prof["attend"][1] >= steps and prof["attend"][1] % steps == 0, (prof, steps)
         assert bool(torch.isfinite(out[..., :8]).all()) and bool(torch.isfinite(out[..., -8:]).all())
         return {"B": B, "dt": dt, "prof": prof, "comm_ms": comm_ms, "q_host": q_host, "out": out,
                 "kept": eng.kept_queries() > 0, "geometry": eng.last_geometry()}
+
+    def per_step(comm_ms, steps):
+        """Exposed communication per step, split per kind of collective (ShardedRange.comm_timing)."""
+        if comm_ms is None:
+            return None
+        return {k: v / steps for k, v in comm_ms.items()}
 
     betas = None if a.sweep is None else [float(v) for v in a.sweep.split(",")]
     m = measure(a.scaling, a.steps, a.warmup)
@@ -395,8 +401,7 @@ def main():
     if world > 1 and a.scaling == "strong" and not a.no_extras and default_workload:
         mw = measure("weak", a.steps, max(1, a.warmup))
         weak = {"value": mw["B"] * world * a.steps / mw["dt"], "ms_per_step": mw["dt"] / a.steps * 1e3,
-                "queries_per_gpu": mw["B"], "comm_ms_exposed_per_step":
-                    None if mw["comm_ms"] is None else mw["comm_ms"] / a.steps}
+                "queries_per_gpu": mw["B"], "comm_ms_exposed_per_step": per_step(mw["comm_ms"], a.steps)}
     control = None
     if world > 1 and sharded and a.scaling == "strong" and not a.no_extras and default_workload:
         # the control experiment of SURVEY.md 8(e): the same batch with the whole bank on every GPU,
@@ -423,6 +428,27 @@ def main():
         control = {"layout": "bank replicated, query-sharded, no collective", "value": Bc * world * a.steps / float(tc.item()),
                    "ms_per_step": float(tc.item()) / a.steps * 1e3, "max_abs_vs_row_sharded": agree}
         engc.close()
+    layouts = None
+    if world > 2 and sharded and row_shards == world and a.scaling == "strong" and not a.no_extras and default_workload:
+        # the 2-D layouts R x Q of the same job (the bank row-sharded over groups of R ranks, Q groups each
+        # serving its own queries: collectives span R ranks, shards are W/R times larger) in the same
+        # invocation, next to the north-star layout W x 1 that `value` reports
+        layouts = {}
+        for R in [r for r in range(2, world) if world % r == 0]:
+            g2, si2, _ = make_layout(R)
+            r0, r1 = shard_rows(N, R, si2)
+            e2 = _native.HipEngine(dev)
+            e2.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases, sh_table=table)
+            sh2 = bank.rows(r0, r1)
+            e2.set_bank(sh2.keys, sh2.values, sh2.xyz, r0)
+            m2 = measure("strong", a.steps, max(1, a.warmup), eng=e2,
+                         model=ShardedRange(e2, "RANGE+", a.beta, group=g2, n_chunks=a.shard_chunks or None), sharded=True)
+            layouts[f"{R}x{world // R}"] = {
+                "value": m2["B"] * world * a.steps / m2["dt"], "ms_per_step": m2["dt"] / a.steps * 1e3,
+                "bank_rows_per_gpu": r1 - r0, "comm_ms_exposed_per_step": per_step(m2["comm_ms"], a.steps),
+                "max_abs_vs_row_sharded": float((m2["out"] - m["out"]).abs().max())}
+            del m2
+            e2.close()
     scan = None
     host_contract = None
     opt_in = None
@@ -512,12 +538,15 @@ def main():
             res["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "layout": a.layout if world > 1 else "row-sharded (forced, one rank)",
                            "row_shards": row_shards if sharded else 1, "query_groups": world // row_shards if sharded else world,
-                           "comm_ms_exposed_per_step":
-                               None if m["comm_ms"] is None else m["comm_ms"] / a.steps}
+                           "comm_ms_exposed_per_step": per_step(m["comm_ms"], a.steps)}
         if weak is not None:
             res["weak"] = weak
         if control is not None:
             res["control_query_sharded"] = control
+        if layouts:
+            res["layouts"] = layouts
+            best = max(layouts, key=lambda k: layouts[k]["value"])
+            res["best_2d_layout"] = {"layout": best, **layouts[best]}
         if scan is not None:
             res["roofline_scan"] = scan
         if host_contract is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 6
+#define RANGE_ABI_VERSION 7
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -188,7 +188,26 @@ int range_scan_stats(range_ctx* ctx, const float* ehat32_dev, const float* xq32_
                      float* topk_val_dev, int64_t* topk_idx_dev, int32_t keep_logits,
                      range_stream_t stream);
 
-/* Number of queries whose logits the last range_scan_stats kept (0: none). */
+/* Pass 1 in CHUNKS of one scan (row-sharded banks, range_amd/dist.py: the gather of chunk c + 1
+ * and the exchange of chunk c's statistics travel while chunk c + 1 / c is being scanned; no
+ * reference counterpart).  Queries [first_query, first_query + B) of a scan of `total_queries`
+ * queries; their logits are kept at that offset of ONE workspace sized for the whole scan, so that
+ * range_attend_kept(first, ...) addresses the scan's queries as if one range_scan_stats call had
+ * kept them.  first_query must be a multiple of 64; the call with first_query == 0 starts a scan
+ * (and decides, as range_scan_stats does, whether the logits fit), later calls extend it in order
+ * (first_query == range_kept_queries(); otherwise - or when the first call could not keep - the
+ * statistics are still computed and nothing is kept).
+ *   n_splits   : bank splits of this launch (0: chosen from this call's geometry).  The float32 sums l
+ *                depend on the split boundaries: a caller that wants the statistics of a query not to
+ *                depend on how its scan was chunked passes the same value for every chunk
+ *                (range_p1_splits(ctx, B) = what a call of B queries would choose). */
+int range_scan_stats_at(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
+                        float tau_sem, float tau_geo, float* stats_dev, int64_t first_query,
+                        int64_t total_queries, int32_t n_splits, range_stream_t stream);
+int32_t range_p1_splits(const range_ctx* ctx, int64_t B);
+
+/* Number of queries whose logits the last range_scan_stats (or the range_scan_stats_at calls of the
+ * current scan so far) kept (0: none). */
 int64_t range_kept_queries(const range_ctx* ctx);
 
 /* Small-batch top-k, the HBM-streaming form of the keys scan (no reference counterpart; north star:

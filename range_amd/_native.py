@@ -37,6 +37,7 @@ SYMBOLS = (
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
     "range_set_pv_mode", "range_get_pv_mode", "range_set_keys", "range_debug_raise_async_error",
+    "range_scan_stats_at", "range_p1_splits",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -80,6 +81,9 @@ def load_library() -> C.CDLL:
     lib.range_bank_rows.restype = i64
     lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.range_scan_stats.argtypes = [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp, vp, i32, vp]
+    lib.range_scan_stats_at.argtypes = [vp, vp, vp, i64, f32, f32, vp, i64, i64, i32, vp]
+    lib.range_p1_splits.argtypes = [vp, i64]
+    lib.range_p1_splits.restype = i32
     lib.range_attend_kept.argtypes = [vp, i64, vp, i64, f32, f32, f32, vp, vp, vp]
     lib.range_kept_queries.argtypes = [vp]
     lib.range_kept_queries.restype = i64
@@ -105,7 +109,7 @@ def load_library() -> C.CDLL:
     lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 6:
+    if lib.range_abi_version() != 7:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
     flags = lib.range_build_flags().decode()
     if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":
@@ -304,8 +308,28 @@ class HipEngine:
                                                    self._stream()))
         return (stats, tv, ti) if topk else stats
 
+    def scan_stats_at(self, e32: torch.Tensor, xq: torch.Tensor, tau_sem: float, tau_geo: float,
+                      first_query: int, total_queries: int, n_splits: int = 0) -> torch.Tensor:
+        """Pass 1 for queries [first_query, first_query + len(e32)) of a scan of ``total_queries``
+        queries done in chunks; the chunks' logits are kept in ONE workspace that ``attend_kept``
+        addresses as if a single ``scan_stats`` had kept them (range_hip.h: range_scan_stats_at).
+        ``n_splits``: the bank splits of the launch (0: by this chunk's geometry; ``p1_splits``)."""
+        self._t(e32, torch.float32, (KEY_DIM,))
+        self._t(xq, torch.float32, (4,))
+        B = e32.shape[0]
+        stats = self._empty((B, 4), torch.float32)
+        _check(self.lib, self.lib.range_scan_stats_at(self._h, e32.data_ptr(), xq.data_ptr(), B, tau_sem,
+                                                      tau_geo, stats.data_ptr(), first_query, total_queries,
+                                                      n_splits, self._stream()))
+        return stats
+
+    def p1_splits(self, n_queries: int) -> int:
+        """The bank splits a pass-1 launch of ``n_queries`` queries chooses."""
+        return int(self.lib.range_p1_splits(self._h, n_queries))
+
     def kept_queries(self) -> int:
-        """Queries whose logits the last scan_stats(keep_logits=True) kept (0: none)."""
+        """Queries whose logits the last scan_stats(keep_logits=True) - or the scan_stats_at calls of
+        the current scan so far - kept (0: none)."""
         return int(self.lib.range_kept_queries(self._h))
 
     def attend_kept(self, first_query: int, xq: torch.Tensor, tau_sem: float, tau_geo: float,
@@ -386,13 +410,19 @@ class HipEngine:
                                                self._stream()))
         return out
 
-    def finalize(self, partials: torch.Tensor, e64: torch.Tensor) -> torch.Tensor:
+    def finalize(self, partials: torch.Tensor, e64: torch.Tensor,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if partials.dim() == 2:
             partials = partials.unsqueeze(0)
         P, B = partials.shape[0], partials.shape[1]
         self._t(partials, torch.float32, (B, VAL_DIM))
         self._t(e64, torch.float64, (KEY_DIM,))
-        out = self._empty((B, OUT_DIM), torch.float64)
+        if out is None:
+            out = self._empty((B, OUT_DIM), torch.float64)
+        elif out.shape[0] != B:
+            raise ValueError("out must have one row per query")
+        else:
+            self._t(out, torch.float64, (OUT_DIM,))
         _check(self.lib, self.lib.range_finalize(self._h, partials.data_ptr(), P, e64.data_ptr(),
                                                  B, out.data_ptr(), self._stream()))
         return out

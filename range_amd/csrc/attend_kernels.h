@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256) void scan_stats_kernel(ScanArgs a) {
             // three A/B pairs, 10 000 queries: pass 1 3.937 -> 3.916 ms, the pass 2 behind it 14.690 ->
             // 14.616 ms; -DRANGE_EXP_P1_TSTORE restores the default policy)
 #ifdef RANGE_EXP_P1_TSTORE
-            *reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
+            *reinterpret_cast<f32x4*>(a.logits + logit_tile((int64_t)qt + a.qt_offset, a.n_blocks, b0 + t, wave) + 4 * lane) = ss;
 #else
-            __builtin_nontemporal_store(ss, reinterpret_cast<f32x4*>(a.logits + logit_tile(qt, a.n_blocks, b0 + t, wave) + 4 * lane));
+            __builtin_nontemporal_store(ss, reinterpret_cast<f32x4*>(a.logits + logit_tile((int64_t)qt + a.qt_offset, a.n_blocks, b0 + t, wave) + 4 * lane));
 #endif
         // statistics of this tile.  Only the bank's last block can hold pad rows: every other
         // tile takes the unmasked form

@@ -73,7 +73,7 @@ struct range_ctx {
     // logits kept by the last range_scan_stats(keep_logits = 1): kept_B queries x kept_blocks
     // bank blocks, 1 KB tiles (attend_kernels.h: logit_tile); kept_B == 0: nothing kept
     DevBuf<float> ws_logits, ws_rowmax, ws_theta;
-    int64_t kept_B = 0;
+    int64_t kept_B = 0, kept_total = 0;
     int32_t kept_blocks = 0;
     bool allow_keep = true;   // RANGE_KEEP_LOGITS=0 in the environment: never keep (pass 2 recomputes)
     bool warned_no_keep = false;
@@ -856,17 +856,29 @@ int range_blend(range_ctx* c, const float* G, const float* H, float beta, int64_
     return RANGE_OK;
 }
 
-int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
-                     float tau_geo, float* stats, int topk, float* topk_val, int64_t* topk_idx,
-                     int32_t keep_logits, range_stream_t stream) {
+// first_query / total_queries / force_splits: range_scan_stats_at (a scan in chunks whose
+// kept logits share one workspace); a plain range_scan_stats is the chunk [0, B) of a scan of B.
+static int scan_stats_impl(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                           float tau_geo, float* stats, int topk, float* topk_val, int64_t* topk_idx,
+                           int32_t keep_logits, int64_t first_query, int64_t total_queries, int32_t force_splits,
+                           range_stream_t stream) {
     if (!c || !ehat32 || !xq32 || !stats) return fail(RANGE_ERR_INVALID, "null argument");
     if (topk < 0 || topk > MAX_TOPK) return fail(RANGE_ERR_INVALID, "topk must be in [0,%d]", MAX_TOPK);
     if (topk > 0 && (!topk_val || !topk_idx)) return fail(RANGE_ERR_INVALID, "topk outputs null");
+    if (first_query < 0 || first_query % QTILE != 0)
+        return fail(RANGE_ERR_INVALID, "first_query must be a non-negative multiple of %d", QTILE);
+    if (B > 0 && first_query + B > total_queries)
+        return fail(RANGE_ERR_INVALID, "queries [%lld, %lld) exceed the scan's %lld", (long long)first_query,
+                    (long long)(first_query + B), (long long)total_queries);
+    if (force_splits < 0) return fail(RANGE_ERR_INVALID, "n_splits must be >= 0");
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     ScanArgs a{};
     hipStream_t s = (hipStream_t)stream;
-    c->kept_B = 0;
+    // a later chunk extends the scan only in order, and only when the first chunk could keep
+    const bool extends = first_query > 0 && c->kept_B == first_query && c->kept_total == total_queries;
+    if (first_query > 0 && !extends) keep_logits = 0;
+    if (!extends) c->kept_B = 0;
     // small batches are HBM-bound: many splits so that every CU streams a share of the keys
     const bool few = B <= 4 * QTILE;
     // The logits of this call are written to HBM when the caller asks for them (plain scan) or
@@ -875,8 +887,11 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     // 4 B per (query, bank row) of this context's shard; not done when that would take more than
     // half of the free device memory (pass 2 then recomputes, top-k uses the in-scan lists).
     bool write_logits = c->allow_keep && (topk > 0 ? B > RANGE_TOPK_INSCAN_MAX : keep_logits != 0);
-    const int64_t n_qtiles = (B + QTILE - 1) / QTILE, n_blocks = (c->n_rows + BLK - 1) / BLK;
-    if (write_logits) {
+    const int64_t n_qtiles = (total_queries + QTILE - 1) / QTILE, n_blocks = (c->n_rows + BLK - 1) / BLK;
+    if (write_logits && extends) {
+        // (the workspace was sized for the whole scan by its first chunk)
+        if ((size_t)n_qtiles * n_blocks * 1024 > c->ws_logits.n || c->kept_blocks != n_blocks) { write_logits = false; c->kept_B = 0; }
+    } else if (write_logits) {
         const size_t need = (size_t)n_qtiles * n_blocks * 1024;
         if (need > c->ws_logits.n) {        // (hipMemGetInfo is slow: only when growing)
             size_t free_b = 0, total_b = 0;
@@ -901,7 +916,9 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
     int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, true,
                             topk_scan ? (few ? 256 : 16) : (few ? 2048 : 128));
     if (rc) return rc;
+    if (force_splits > 0) a.n_splits = std::max(1, std::min<int>(force_splits, std::max(1, a.n_blocks / 4)));
     if (write_logits) a.logits = c->ws_logits.p;
+    a.qt_offset = (int32_t)(first_query / QTILE);
     if (topk_from_kept) {
         HIP_TRY(c->ws_rowmax.ensure((size_t)a.n_splits * B * 4));
         HIP_TRY(c->ws_theta.ensure((size_t)B));
@@ -933,7 +950,8 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
 #undef RANGE_SCAN_LAUNCH
     HIP_TRY(hipGetLastError());
     if (a.logits && keep_logits) {
-        c->kept_B = B;
+        c->kept_B = first_query + B;
+        c->kept_total = total_queries;
         c->kept_blocks = a.n_blocks;
     }
     const int tpb = 256;
@@ -970,6 +988,27 @@ int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64
         HIP_TRY(hipGetLastError());
     }
     return RANGE_OK;
+}
+
+int range_scan_stats(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                     float tau_geo, float* stats, int topk, float* topk_val, int64_t* topk_idx,
+                     int32_t keep_logits, range_stream_t stream) {
+    return scan_stats_impl(c, ehat32, xq32, B, tau_sem, tau_geo, stats, topk, topk_val, topk_idx, keep_logits,
+                           0, B, 0, stream);
+}
+
+int range_scan_stats_at(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
+                        float tau_geo, float* stats, int64_t first_query, int64_t total_queries,
+                        int32_t n_splits, range_stream_t stream) {
+    return scan_stats_impl(c, ehat32, xq32, B, tau_sem, tau_geo, stats, 0, nullptr, nullptr, /*keep_logits=*/1,
+                           first_query, total_queries, n_splits, stream);
+}
+
+// the bank splits a pass-1 launch of B queries chooses (fill_scan_args, no top-k)
+int32_t range_p1_splits(const range_ctx* c, int64_t B) {
+    if (!c || !c->has_bank || B <= 0) return 0;
+    const int n_qtiles = (int)((B + QTILE - 1) / QTILE), n_blocks = (int)((c->n_rows + BLK - 1) / BLK);
+    return choose_splits(n_qtiles, n_blocks, c->n_cu, RANGE_P1_WG_PER_CU, B <= 4 * QTILE ? 2048 : 128);
 }
 
 // repeats > 1 (range_topk_stream_timed): the whole call's launches are enqueued `repeats` times

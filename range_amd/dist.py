@@ -6,18 +6,23 @@ holds bank rows [r*N/W, (r+1)*N/W) and serves its own B queries; the soft-attent
 decomposes exactly over row shards:
 
     1. encode the local queries (kernel A)                       no communication
-    2. ONE all-gather of the packed query operands e32 (B,256) | xq (B,4): W*B*1040 B per rank
+    2. all-gather of the query operands e32 (B,256) and xq (B,4): W*B*1040 B per rank
     3. pass 1 on the local shard for ALL W*B queries -> softmax statistics (m, l) with the
        constant shift m = tau*log2(e) (unit-vector logits), so the l of disjoint shards ADD
-    4. all-reduce(sum) of the l columns (W*B,2)                   8 B per query
+    4. all-gather of the statistics (W*B,4) + merge in rank order (same m, the l add: a fixed
+       order, where an all-reduce's would depend on an element's place in the buffer)
     5. pass 2 on the local shard with the GLOBAL statistics -> partial (W*B,1024) f32; partials
        of different shards simply add because the weights are already globally normalised
     6. all-to-all: rank r receives the W partial slices of ITS queries (one direct transfer per
        peer, so all 7 xGMI links of a GPU carry 1/7 of the traffic each - not a ring)
     7. finalize: fixed-order sum of the W slices + pack with e64 -> (B,1280) float64
 
-Steps 5-7 run per query chunk: the all-to-all of chunk c is asynchronous (RCCL's own stream) and
-overlaps pass 2 of chunk c+1, so only the last chunk's exchange is exposed.
+Steps 2-7 run per query CHUNK and every collective is asynchronous (RCCL's own stream): the
+gathers of all chunks are issued behind the encoder, pass 1 of chunk c runs while the gather of
+chunk c+1 and the statistics of chunk c-1 travel, pass 2 of chunk c while the exchange of chunk c-1
+travels.  Exposed on the compute stream: the first chunk's gather and the last chunk's exchange.
+Pass 1 keeps the logits of all chunks in ONE workspace (range_scan_stats_at), every chunk with the
+same bank-split count, so a query's statistics - and the result - do not depend on the chunking.
 
 The top-k side channel merges per-shard candidate lists with ONE all-gather (north star).
 
@@ -43,12 +48,15 @@ def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 class ShardedRange:
     """RANGE / RANGE+ forward over a row-sharded bank.  ``engine`` holds THIS rank's rows."""
 
-    #: queries per rank and chunk below which a forward is not split further.  A chunk's exchange
-    #: hides behind the next chunk's pass 2, but splitting pass 2 costs too (two launches of 5 000
-    #: scanned queries against a 12 500-row shard: 2 x 0.986 ms instead of 1.913 ms): worth it
-    #: where a rank ships >= 8 MB to each peer (2 ranks in the strong mode, any count in the weak
-    #: mode), a wash at 4 and 8 ranks in the strong mode (tools/shard_emulate.py --chunks)
-    min_chunk = 2048
+    #: queries per rank and chunk below which a forward is not split further.  Chunks buy overlap -
+    #: the statistics of chunk c travel under pass 1 of chunk c+1, its exchange under pass 2 of chunk
+    #: c+1, so only the first gather and the last exchange are exposed - and cost launches: what a rank
+    #: of 8 computes for BASELINE's 10 000-query batch (1 250 own, 10 000 scanned against 12 500 rows;
+    #: tools/shard_emulate.py --chunks k 8, round 4) takes 2.885 ms as one chunk, 3.011 ms as two,
+    #: 3.119 ms as four.  Default: TWO chunks from 1 024 queries per rank (three blocking
+    #: collectives -> one gather + half an exchange exposed), four from 8 192 (the weak mode, where a
+    #: rank ships >= 8 MB per peer and chunk)
+    min_chunk = 512
 
     def __init__(self, engine, model_name: str = "RANGE+", beta: Optional[float] = 0.5,
                  group=None, n_chunks: Optional[int] = None):
@@ -62,12 +70,26 @@ class ShardedRange:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.n_chunks = n_chunks   # None: 4 chunks when there is a peer to exchange with
+        self.n_chunks = n_chunks   # None: 2 or 4 chunks (by batch size) when there is a peer to exchange with
         # gathered / chunk-major / receive buffers: one per name, sized to the largest request seen
         # (a step then makes no allocation of its own besides the engine's outputs)
         self._bufs = {}
         self._timing = False
-        self._events = []
+        self._events = {}
+        #: pass 1 per chunk with its collectives overlapped (needs engine.scan_stats_at); False: one
+        #: pass 1 over all scanned queries between a blocking gather and a blocking all-reduce (A/B, tests)
+        self.pass1_chunked = hasattr(engine, "scan_stats_at")
+        #: bytes this rank SENT / RECEIVED per kind of collective since ``reset_bytes()`` (payload
+        #: sizes; "results" = what the batch drivers move to rank 0, range.ShardedLocationEncoder)
+        self.bytes_sent = {}
+        self.bytes_received = {}
+
+    def reset_bytes(self):
+        self.bytes_sent, self.bytes_received = {}, {}
+
+    def _count(self, kind: str, sent: int, received: int):
+        self.bytes_sent[kind] = self.bytes_sent.get(kind, 0) + int(sent)
+        self.bytes_received[kind] = self.bytes_received.get(kind, 0) + int(received)
 
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
         """One flat buffer per (name, dtype, device), grown to the largest request seen; a request is
@@ -85,21 +107,25 @@ class ShardedRange:
     # -- exposed communication time ------------------------------------------------------------
     def comm_timing(self, on: bool):
         """``comm_timing(True)`` starts measuring, ``comm_timing(False)`` stops and returns the
-        milliseconds the COMPUTE stream spent blocked on collectives since (event pairs around
-        every point where it waits for one: the time a collective - including the wait for the
-        slowest peer - is not hidden behind this rank's kernels).  None without a GPU."""
+        milliseconds the COMPUTE stream spent blocked on collectives since, per kind - a dict
+        {"gather", "reduce", "exchange", "total"} (event pairs around every point where the stream
+        waits for one: the time a collective - including the wait for the slowest peer - is not
+        hidden behind this rank's kernels).  None without a GPU."""
         if on:
-            self._events, self._timing = [], torch.cuda.is_available()
+            self._events, self._timing = {}, torch.cuda.is_available()
             return None
         if not self._timing:
             return None
         self._timing = False
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self._events)
-        self._events = []
+        ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self._events.items()}
+        for k in ("gather", "reduce", "exchange"):
+            ms.setdefault(k, 0.0)
+        ms["total"] = sum(ms.values())
+        self._events = {}
         return ms
 
-    def _blocked(self, fn):
+    def _blocked(self, kind: str, fn):
         """Run ``fn`` (something that makes the current stream wait for a collective) between two
         events on the current stream."""
         if not self._timing:
@@ -108,7 +134,7 @@ class ShardedRange:
         a.record()
         r = fn()
         b.record()
-        self._events.append((a, b))
+        self._events.setdefault(kind, []).append((a, b))
         return r
 
     def _staged(self, t: torch.Tensor) -> bool:
@@ -123,11 +149,52 @@ class ShardedRange:
             src = src.cpu()
         out = self._buf("gather:" + name, (self.world * t.shape[0],) + tuple(t.shape[1:]), t.dtype,
                         src.device)
-        self._blocked(lambda: dist.all_gather_into_tensor(out, src, group=self.group))
+        self._blocked("gather", lambda: dist.all_gather_into_tensor(out, src, group=self.group))
+        nb = src.numel() * src.element_size()
+        self._count("gather", nb * (self.world - 1), nb * (self.world - 1))
         return out.to(t.device).reshape((self.world,) + tuple(t.shape))
+
+    def _gather_start(self, src: torch.Tensor, dst: torch.Tensor):
+        """Start the all-gather of ``src`` (n, d) into ``dst`` (W*n, d), rank-major: returns a
+        function that makes the current stream wait for it (and, staged, lands the host copy)."""
+        nb = src.numel() * src.element_size()
+        self._count("gather", nb * (self.world - 1), nb * (self.world - 1))
+        if self._staged(src):
+            h_src = src.cpu()
+            h_dst = torch.empty(dst.shape, dtype=dst.dtype)
+            work = dist.all_gather_into_tensor(h_dst, h_src, group=self.group, async_op=True)
+
+            def land():
+                work.wait()
+                dst.copy_(h_dst)
+            return land
+        work = dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True)
+        return work.wait
+
+    def _stats_start(self, stats: torch.Tensor, name: str):
+        """Start the all-gather of a chunk's statistics (n,4) and return the function that waits for
+        it and merges the W shards' rows in rank order (engine.merge_stats: same shift m, the l add).
+        Not an all-reduce: a ring or tree sums an element in an order that depends on where it sits
+        in the buffer, so a query's l - and with it the result - would change in the last bit with
+        the batch it travels in; the fixed-order merge keeps the sharded result independent of the
+        chunking and of the collective algorithm (8 B x W per query and chunk, one small kernel)."""
+        out = self._buf("gather:" + name, (self.world * stats.shape[0], stats.shape[1]), stats.dtype,
+                        torch.device("cpu") if self._staged(stats) else stats.device)
+        nb = stats.numel() * stats.element_size()
+        self._count("reduce", nb * (self.world - 1), nb * (self.world - 1))
+        src = stats.cpu() if self._staged(stats) else stats
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+
+        def merged():
+            work.wait()
+            parts = out.to(stats.device).view(self.world, stats.shape[0], stats.shape[1])
+            return self.engine.merge_stats(parts)
+        return merged
 
     def _all_to_all(self, part: torch.Tensor, name: str):
         """Start the exchange of a chunk's partials; returns (work, getter of the received tensor)."""
+        nb = part.numel() * part.element_size() // self.world * (self.world - 1)
+        self._count("exchange", nb, nb)
         if self._staged(part):
             src = part.cpu()
             recv = torch.empty_like(src)
@@ -140,18 +207,10 @@ class ShardedRange:
         return work, (lambda: recv), part
 
     def _reduce_stats(self, stats_local: torch.Tensor) -> torch.Tensor:
-        """Global softmax statistics from the shards': every shard reports (m, l) with the SAME
-        constant shift m (range_hip.h: range_scan_stats), so the sums l of disjoint row sets
-        add - one all-reduce of the two l columns, in place of an all-gather and a merge kernel."""
-        l = stats_local[:, 1::2].contiguous()
-        if self._staged(l):
-            h = l.cpu()
-            self._blocked(lambda: dist.all_reduce(h, group=self.group))
-            l = h.to(stats_local.device)
-        else:
-            self._blocked(lambda: dist.all_reduce(l, group=self.group))
-        stats_local[:, 1::2] = l
-        return stats_local
+        """Global softmax statistics from the shards' (the blocking form of the unchunked pass 1):
+        every shard reports (m, l) with the SAME constant shift m (range_hip.h: range_scan_stats),
+        so the sums l of disjoint row sets add - gathered and merged in rank order (``_stats_start``)."""
+        return self._blocked("reduce", self._stats_start(stats_local, "stats"))
 
     def _gather_queries(self, lonlat: torch.Tensor):
         """Encode the own queries and gather every rank's scan operands: e32 (B,256) and xq (B,4)
@@ -186,46 +245,86 @@ class ShardedRange:
         """Row ranges [lo,hi) of a rank's queries per chunk.  Boundaries are multiples of 64 (the
         query-tile size: a chunk then starts on a tile of the kept logits)."""
         W = self.world
-        n_chunks = self.n_chunks if self.n_chunks else (4 if W > 1 else 1)
+        n_chunks = self.n_chunks if self.n_chunks else ((4 if B >= 8192 else 2) if W > 1 else 1)
         n_chunks = max(1, min(n_chunks, B // self.min_chunk))
         cuts = sorted({min(B, ((B * c) // n_chunks + 32) // 64 * 64) for c in range(1, n_chunks)})
         bounds = [0] + [c for c in cuts if 0 < c < B] + [B]
         return list(zip(bounds[:-1], bounds[1:]))
 
-    @torch.no_grad()
-    def forward(self, lonlat: torch.Tensor) -> torch.Tensor:
-        """lonlat: this rank's (B,2) float64 queries (same B on every rank).
-        Returns this rank's (B,1280) float64 embeddings (device tensor)."""
+    def _scan(self, lonlat: torch.Tensor):
+        """Steps 1-4 for this rank's (B,2) queries.  Returns (e64 of the own queries, e32 and xq of
+        ALL W*B scanned queries in chunk-major order, the chunk bounds, one function per chunk that
+        returns the chunk's GLOBAL statistics once the current stream may read them, and whether pass 2
+        finds the scan's logits kept)."""
         W, B = self.world, lonlat.shape[0]
-        e64, e32_all, xq_all = self._gather_queries(lonlat)
+        eng = self.engine
         chunks = self._chunk_bounds(B)
-        e32_all = self._chunk_major(e32_all, chunks, "e32")
-        xq_all = self._chunk_major(xq_all, chunks, "xq")
-        # pass 1 on the local shard keeps its logits; pass 2 reads them back instead of
-        # recomputing e . K^T (they are independent of the global statistics)
-        stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
-                                             keep_logits=True)
-        kept = self.engine.kept_queries() == W * B
-        stats = self._reduce_stats(stats_local)
+        if not self.pass1_chunked:
+            e64, e32_all, xq_all = self._gather_queries(lonlat)
+            e32_all = self._chunk_major(e32_all, chunks, "e32")
+            xq_all = self._chunk_major(xq_all, chunks, "xq")
+            n_max = W * max(hi - lo for lo, hi in chunks)
+            if hasattr(eng, "scan_stats_at"):
+                # (the same bank splits as the chunked form: bit-identical statistics)
+                stats_local = eng.scan_stats_at(e32_all, xq_all, self.tau_sem, self.tau_geo, 0, W * B,
+                                                n_splits=eng.p1_splits(n_max))
+            else:
+                # pass 1 on the local shard keeps its logits; pass 2 reads them back instead of
+                # recomputing e . K^T (they are independent of the global statistics)
+                stats_local = eng.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo, keep_logits=True)
+            stats = self._reduce_stats(stats_local)
+            getters = [(lambda lo=lo, hi=hi: stats[W * lo:W * hi]) for lo, hi in chunks]
+            return e64, e32_all, xq_all, chunks, getters, eng.kept_queries() == W * B
+        e64, e32, xq = eng.encode(lonlat)
+        total = W * B
+        e32_all = self._buf("cm:e32", (total, e32.shape[1]), e32.dtype, e32.device)
+        xq_all = self._buf("cm:xq", (total, xq.shape[1]), xq.dtype, xq.device)
+        # every chunk's gather is issued now: a chunk's rows of all ranks land rank-major in rows
+        # [W lo, W hi) - the chunk-major order of the scan, no copy
+        landed = [(self._gather_start(e32[lo:hi], e32_all[W * lo:W * hi]),
+                   self._gather_start(xq[lo:hi], xq_all[W * lo:W * hi])) for lo, hi in chunks]
+        n_splits = eng.p1_splits(W * max(hi - lo for lo, hi in chunks))
+        getters = []
+        for (lo, hi), (we, wx) in zip(chunks, landed):
+            self._blocked("gather", we)
+            self._blocked("gather", wx)
+            first, n = W * lo, W * (hi - lo)
+            st = eng.scan_stats_at(e32_all[first:first + n], xq_all[first:first + n], self.tau_sem, self.tau_geo,
+                                   first, total, n_splits=n_splits)
+            merged = self._stats_start(st, f"stats{len(getters)}")
+            getters.append(lambda merged=merged: self._blocked("reduce", merged))
+        return e64, e32_all, xq_all, chunks, getters, eng.kept_queries() == total
+
+    @torch.no_grad()
+    def forward(self, lonlat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """lonlat: this rank's (B,2) float64 queries (same B on every rank).
+        Returns this rank's (B,1280) float64 embeddings (device tensor; ``out`` when given: the
+        chunks are finalized straight into its rows)."""
+        W = self.world
+        e64, e32_all, xq_all, chunks, stats_of, kept = self._scan(lonlat)
         pending = []
         for ci, (lo, hi) in enumerate(chunks):
             first, n = W * lo, W * (hi - lo)
+            stats = stats_of[ci]()
             if kept:
                 part = self.engine.attend_kept(first, xq_all[first:first + n], self.tau_sem,
-                                               self.tau_geo, self.beta, stats[first:first + n])
+                                               self.tau_geo, self.beta, stats)
             else:
                 part = self.engine.attend(e32_all[first:first + n], xq_all[first:first + n],
-                                          self.tau_sem, self.tau_geo, self.beta,
-                                          stats[first:first + n])
+                                          self.tau_sem, self.tau_geo, self.beta, stats)
             work, get, keep = self._all_to_all(part, f"fwd{ci}")
             pending.append((work, get, keep, lo, hi))
-        outs = []
+        if out is None:
+            out = torch.empty((lonlat.shape[0], e64.shape[1] + 1024), dtype=torch.float64, device=e64.device)
+        into = hasattr(self.engine, "scan_stats_at")      # (engines of the round-3 duck type return a new tensor)
         for work, get, keep, lo, hi in pending:
-            self._blocked(work.wait)
-            recv = get()
-            outs.append(self.engine.finalize(recv.reshape(W, hi - lo, recv.shape[1]),
-                                             e64[lo:hi].contiguous()))
-        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+            self._blocked("exchange", work.wait)
+            recv = get().reshape(W, hi - lo, -1)
+            if into:
+                self.engine.finalize(recv, e64[lo:hi], out=out[lo:hi])
+            else:
+                out[lo:hi] = self.engine.finalize(recv, e64[lo:hi].contiguous())
+        return out
 
     __call__ = forward
 
@@ -251,6 +350,10 @@ class ShardedRange:
         B = lonlat.shape[0]
         if b_max is None:      # (a caller that knows every rank brings the same count passes it: no collective)
             b_max = self._max_over_ranks(B, lonlat.device)
+        elif B > b_max:
+            # (rows beyond b_max would never be computed; b_max must be the SAME on every rank of the
+            # group - the steps' collectives are shaped by it - and cover every rank's count)
+            raise ValueError(f"this rank brings {B} queries but b_max={b_max}")
         if chunk is None:
             chunk = max(64, self.scan_chunk // self.world // 64 * 64)
         chunk = max(1, int(chunk))
@@ -277,6 +380,9 @@ class ShardedRange:
         if out is None:
             out = torch.empty((B, 1280), dtype=torch.float64, device=lonlat.device)
         for lo, n_own, q in self._steps(lonlat, chunk, b_max):
+            if n_own == q.shape[0]:
+                self.forward(q, out=out[lo:lo + n_own])      # (no padding: straight into the result)
+                continue
             res = self.forward(q)
             if n_own:
                 out[lo:lo + n_own] = res[:n_own]
@@ -321,33 +427,27 @@ class ShardedRange:
             raise ValueError("sweep() is defined for RANGE+ only")
         betas = [float(b) for b in betas]
         W, B = self.world, lonlat.shape[0]
-        e64, e32_all, xq_all = self._gather_queries(lonlat)
-        chunks = self._chunk_bounds(B)
-        e32_all = self._chunk_major(e32_all, chunks, "e32")
-        xq_all = self._chunk_major(xq_all, chunks, "xq")
-        stats_local = self.engine.scan_stats(e32_all, xq_all, self.tau_sem, self.tau_geo,
-                                             keep_logits=True)
-        kept = self.engine.kept_queries() == W * B
-        stats = self._reduce_stats(stats_local)
+        e64, e32_all, xq_all, chunks, stats_of, kept = self._scan(lonlat)
         pending = []
         for ci, (lo, hi) in enumerate(chunks):
             first, n = W * lo, W * (hi - lo)
             sl = slice(first, first + n)
+            st = stats_of[ci]()
             parts = []
             for b in (1.0, 0.0):
                 if kept:
                     parts.append(self.engine.attend_kept(first, xq_all[sl], self.tau_sem,
-                                                         self.tau_geo, b, stats[sl]))
+                                                         self.tau_geo, b, st))
                 else:
                     parts.append(self.engine.attend(e32_all[sl], xq_all[sl], self.tau_sem,
-                                                    self.tau_geo, b, stats[sl]))
+                                                    self.tau_geo, b, st))
             ex = [self._all_to_all(p, f"sweep{ci}:{j}") for j, p in enumerate(parts)]
             pending.append((ex, lo, hi))
         out = torch.empty((len(betas), B, e64.shape[1] + 1024), dtype=torch.float64,
                           device=e64.device)
         for ex, lo, hi in pending:
             for work, _, _ in ex:
-                self._blocked(work.wait)
+                self._blocked("exchange", work.wait)
             rH, rG = ex[0][1](), ex[1][1]()
             e = e64[lo:hi].contiguous()
             for j, b in enumerate(betas):
@@ -385,20 +485,32 @@ def make_layout(row_shards: int, group=None):
     R = 1 is the query-sharded control (no collective on the data path); in between the collectives
     span R ranks only, the all-to-all is (R - 1) transfers per rank, a shard has N / R rows (pass 2
     keeps its whole-round efficiency on bigger shards) and a rank scans R times its own queries
-    instead of W times.  Every rank of `group` must call this (the sub-groups are created
-    collectively).  Returns (shard_group, shard_index, query_group_index)."""
+    instead of W times.  With the default group (``group=None``) every rank of the job must call
+    this: the sub-groups are created collectively, each rank entering every ``new_group``.  With a
+    sub-group of the job as ``group`` only ITS ranks need to call (they cannot make the other
+    ranks enter ``new_group``): each creates just its own shard group with torch's local
+    synchronisation.  Returns (shard_group, shard_index, query_group_index)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     R = int(row_shards)
     if R < 1 or world % R:
         raise ValueError(f"row_shards={row_shards} does not divide the {world} ranks")
     if R == world:
         return group, rank, 0
-    ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
-    mine = None
-    for g in range(world // R):
-        sub = dist.new_group(ranks=ranks[g * R:(g + 1) * R])
-        if rank // R == g:
-            mine = sub
+    if group is None or group is dist.group.WORLD:
+        ranks = list(range(world))
+        mine = None
+        for g in range(world // R):
+            sub = dist.new_group(ranks=ranks[g * R:(g + 1) * R])
+            if rank // R == g:
+                mine = sub
+        return mine, rank % R, rank // R
+    ranks = dist.get_process_group_ranks(group)
+    g = rank // R
+    try:
+        mine = dist.new_group(ranks=ranks[g * R:(g + 1) * R], use_local_synchronization=True)
+    except TypeError as ex:       # (a torch without local synchronisation: every rank of the JOB would have to call)
+        raise RuntimeError("row_shards < group size over a non-default process group needs a torch whose "
+                           "new_group() takes use_local_synchronization") from ex
     return mine, rank % R, rank // R
 
 

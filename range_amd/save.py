@@ -109,6 +109,104 @@ class EmbeddingPipeline:
         return out
 
 
+class ShardedEmbeddingPipeline:
+    """The batch driver over a ROW-SHARDED model (``load_model(..., shards=W)``): every rank of the
+    job iterates the same batches; of a batch of n rows rank r embeds rows [n r / W, n (r+1) / W)
+    against all shards (``ShardedRange.embed``: collective inside its shard group) and its (n / W,
+    1280) float64 rows travel to rank 0 ONLY - one gather of 10 KB per own query per rank, where
+    an all-gather of the full result on every rank moves W times that - on RCCL's stream, while the
+    next batch computes; rank 0 copies the gathered batch to pinned memory on a copy stream and
+    yields host arrays in order, two batches behind the compute (as ``EmbeddingPipeline``).  The
+    other ranks yield nothing."""
+
+    def __init__(self, model, depth: int = 2):
+        import torch.distributed as dist
+        self.model, self.dist = model, dist
+        self.device = model.engine.device
+        self.group = model.group
+        self.world, self.rank = model.world, model.rank
+        self.root_global = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self.staged = dist.get_backend(self.group) == "gloo"      # (ranks sharing a GPU in tests: through the host)
+        self.depth = max(2, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._slots = [None] * self.depth       # (send rows, gathered rows on rank 0, pinned copy on rank 0)
+        self._copied = [torch.cuda.Event() for _ in range(self.depth)]
+
+    def _buffers(self, slot: int, per: int):
+        cur = self._slots[slot]
+        if cur is None or cur[0].shape[0] < per:
+            send = torch.empty((per, 1280), dtype=torch.float64, device=self.device)
+            gathered = pinned = None
+            if self.rank == 0:
+                gathered = torch.empty((self.world * per, 1280), dtype=torch.float64, device=self.device)
+                pinned = torch.empty((self.world * per, 1280), dtype=torch.float64).pin_memory()
+            cur = self._slots[slot] = (send, gathered, pinned)
+        send, gathered, pinned = cur
+        W = self.world
+        return send[:per], (None if gathered is None else gathered[:W * per]), (None if pinned is None else pinned[:W * per])
+
+    @torch.no_grad()
+    def run(self, batches: Iterable) -> Iterator[np.ndarray]:
+        W, r, dist = self.world, self.rank, self.dist
+        sharded = self.model.sharded
+        inflight: List[Tuple[int, int, int, object]] = []       # (slot, n, per, host rows when staged)
+        i = 0
+        for coords in batches:
+            x = self.model._coords(coords)
+            n = x.shape[0]
+            if n == 0:
+                continue
+            slot = i % self.depth
+            if len(inflight) == self.depth:
+                res = self._collect(*inflight.pop(0))
+                if r == 0:
+                    yield res
+            per = (n + W - 1) // W                                # the largest per-rank count: no collective to agree on it
+            lo, hi = (n * r) // W, (n * (r + 1)) // W
+            send, gathered, pinned = self._buffers(slot, per)
+            # (b_max: the step count of the shard group's collectives; the same on all its ranks)
+            sharded.embed(x[lo:hi], out=send[:hi - lo], b_max=per)
+            nb = per * 1280 * 8
+            sharded._count("results", 0 if r == 0 else nb, (W - 1) * nb if r == 0 else 0)
+            host = None
+            if self.staged:
+                h = send.cpu()
+                parts = [torch.empty_like(h) for _ in range(W)] if r == 0 else None
+                dist.gather(h, parts, dst=self.root_global, group=self.group)
+                host = parts
+            else:
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(self.copy_stream):
+                    # the gather and the device->host copy behind it wait for THIS batch only; the
+                    # compute stream goes on with the next batch
+                    self.copy_stream.wait_event(done)
+                    parts = list(gathered.view(W, per, 1280).unbind(0)) if r == 0 else None
+                    dist.gather(send, parts, dst=self.root_global, group=self.group)
+                    if r == 0:
+                        pinned.copy_(gathered, non_blocking=True)
+                    self._copied[slot].record(self.copy_stream)
+            inflight.append((slot, n, per, host))
+            i += 1
+        while inflight:
+            res = self._collect(*inflight.pop(0))
+            if r == 0:
+                yield res
+
+    def _collect(self, slot: int, n: int, per: int, host):
+        W = self.world
+        if not self.staged:
+            self._copied[slot].synchronize()       # (every rank: its send buffer is free again)
+        if self.rank != 0:
+            return None
+        out = POOL.take(n, 1280)
+        for r in range(W):
+            lo, hi = (n * r) // W, (n * (r + 1)) // W
+            src = host[r][:hi - lo].numpy() if host is not None else self._slots[slot][2][r * per:r * per + hi - lo].numpy()
+            out[lo:hi] = src
+        return out
+
+
 def save_embeddings(args, train_loader, val_loader, location_model):
     """Drop-in for range/utils/save.py:7-58."""
     embeddings_dir = os.path.join(args.embeddings_dir, args.location_model_name)
@@ -120,22 +218,29 @@ def save_embeddings(args, train_loader, val_loader, location_model):
     location_model.eval()
     if getattr(location_model, "is_sharded", False):
         # row-sharded model (load_model(..., shards=W)): every rank of the job runs this function over
-        # the SAME loaders; model(coords) is collective and returns the full batch on every rank
-        # (range.ShardedLocationEncoder), rank 0 writes the files
+        # the SAME loaders and embeds ITS rows of every batch; the rows travel to rank 0 only, which
+        # writes the files (ShardedEmbeddingPipeline)
         import torch.distributed as dist
+        pipe = ShardedEmbeddingPipeline(location_model)
+        root = dist.get_rank(location_model.group) == 0
         for loader, path in ((train_loader, train_path), (val_loader, val_path)):
-            coords_list, y_list, embeddings_list = [], [], []
-            for coords, y in loader:                                     # range/utils/save.py:24-37
-                coords_list.append(coords.cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords))
-                y_list.append(y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y))
-                embeddings_list.append(location_model(coords))
-            if dist.get_rank(location_model.group) == 0:
+            coords_list, y_list = [], []
+
+            def coords_iter():
+                for coords, y in loader:                                 # range/utils/save.py:24-37
+                    if root:
+                        coords_list.append(coords.cpu().numpy() if torch.is_tensor(coords) else np.asarray(coords))
+                        y_list.append(y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y))
+                    yield coords
+
+            embeddings_list = list(pipe.run(coords_iter()))
+            if root:
                 np.savez(path, coords=np.concatenate(coords_list, axis=0),
                          embeddings=np.concatenate(embeddings_list, axis=0),
                          y=np.concatenate(y_list, axis=0))
                 print(f"File saved to {path}")
         dist.barrier(location_model.group)
-        if dist.get_rank(location_model.group) == 0:
+        if root:
             print(f"File saved to {train_path} and {val_path}")
         return
     pipe = EmbeddingPipeline(location_model)

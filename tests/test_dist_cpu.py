@@ -36,8 +36,12 @@ class OracleShardEngine:
         return torch.from_numpy(e), torch.from_numpy(e.astype(np.float32)), torch.from_numpy(xq)
 
     def _logits(self, e32, xq):
-        s = e32.numpy().astype(np.float64) @ self.bank.keys.astype(np.float64).T
-        g = xq.numpy()[:, :3].astype(np.float64) @ self.bank.xyz.astype(np.float64).T
+        # (row by row: a query's logits must not depend on the batch it is computed in - BLAS picks
+        # its blocking by shape - so that chunked and unchunked scans can be compared bit for bit)
+        K, X = self.bank.keys.astype(np.float64), self.bank.xyz.astype(np.float64)
+        e, x = e32.numpy().astype(np.float64), xq.numpy()[:, :3].astype(np.float64)
+        s = np.stack([K @ r for r in e]) if len(e) else np.zeros((0, K.shape[0]))
+        g = np.stack([X @ r for r in x]) if len(x) else np.zeros((0, X.shape[0]))
         return s, g
 
     def scan_stats(self, e32, xq, tau_sem, tau_geo, topk=0, keep_logits=False):
@@ -58,6 +62,27 @@ class OracleShardEngine:
         tv, ti = O.topk64(s, topk)
         return st, torch.from_numpy(tv.astype(np.float32)), torch.from_numpy(ti + self.row_offset)
 
+    # pass 1 in chunks of one scan (range_hip.h: range_scan_stats_at): the chunks' logits share one
+    # workspace, addressed by attend_kept as if one call had kept them
+    def p1_splits(self, n_queries):
+        return 3
+
+    def scan_stats_at(self, e32, xq, tau_sem, tau_geo, first_query, total_queries, n_splits=0):
+        assert first_query % 64 == 0 and first_query + e32.shape[0] <= total_queries
+        self.calls_at = getattr(self, "calls_at", 0) + 1
+        if first_query == 0:
+            self._kept = torch.zeros((total_queries, e32.shape[1]), dtype=e32.dtype) if self.keep_ok else None
+            self._kept_n = 0
+        if self._kept is not None and self._kept_n == first_query and self._kept.shape[0] == total_queries:
+            self._kept[first_query:first_query + e32.shape[0]] = e32
+            self._kept_n = first_query + e32.shape[0]
+        else:
+            self._kept = None
+        kept, self._kept = self._kept, None
+        st = self.scan_stats(e32, xq, tau_sem, tau_geo)        # (resets self._kept)
+        self._kept = kept
+        return st
+
     def merge_stats(self, parts):
         p = parts.numpy().astype(np.float64)
         out = np.zeros(p.shape[1:], np.float64)
@@ -73,10 +98,13 @@ class OracleShardEngine:
         w = beta * np.exp2(s * tau_sem * LOG2E - st[:, :1]) / st[:, 1:2]
         if tau_geo > 0:
             w = w + (1 - beta) * np.exp2(g * tau_geo * LOG2E - st[:, 2:3]) / st[:, 3:4]
-        return torch.from_numpy((w @ self.bank.values.astype(np.float64)).astype(np.float32))
+        V = self.bank.values.astype(np.float64)
+        return torch.from_numpy(np.stack([r @ V for r in w]).astype(np.float32))
 
     def kept_queries(self):
-        return 0 if self._kept is None else self._kept.shape[0]
+        if self._kept is None:
+            return 0
+        return getattr(self, "_kept_n", None) or self._kept.shape[0]
 
     def attend_kept(self, first, xq, tau_sem, tau_geo, beta, stats):
         assert first % 64 == 0 and first + xq.shape[0] <= self._kept.shape[0]
@@ -85,11 +113,15 @@ class OracleShardEngine:
     def blend(self, G, H, beta):
         return ((1.0 - beta) * G.double() + beta * H.double()).float()
 
-    def finalize(self, partials, e64):
+    def finalize(self, partials, e64, out=None):
         acc = partials[0].clone()
         for p in partials[1:]:
             acc = acc + p
-        return torch.cat([acc.double(), e64], dim=1)
+        res = torch.cat([acc.double(), e64], dim=1)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
 
     def merge_topk(self, vals, idxs):
         W, B, k = vals.shape
@@ -129,6 +161,27 @@ def _worker(rank, world, port, N, B, L, H, ret):
             ref = O.forward(q, w, L, full, name, beta)      # unsharded oracle, own queries
             err = float(np.abs(out - ref).max())
             assert out.shape == (B, 1280) and err < 1e-5, (name, beta, err)   # f32 op-order noise of the reference
+        # pass 1 per chunk, its gathers / all-reduces overlapped, == one pass 1 between blocking
+        # collectives, bit for bit (same bank splits for every chunk; dist.ShardedRange._scan)
+        outs = {}
+        for chunked in (True, False):
+            eng = OracleShardEngine(w, L, shard, r0)
+            model = ShardedRange(eng, "RANGE+", 0.5, n_chunks=3)
+            model.min_chunk = 2
+            assert model.pass1_chunked
+            model.pass1_chunked = chunked
+            outs[chunked] = model(torch.from_numpy(q)).numpy()
+            assert eng.calls_at == (3 if chunked else 1) and eng.kept_queries() == world * B
+            sw = model.sweep(torch.from_numpy(q), (0.0, 1.0)).numpy()
+            outs[chunked, "sweep"] = sw
+            # bytes this rank moved: gathers of 1040 B per query to W-1 peers, 16 B of statistics per
+            # scanned query to every peer, 4 KB of partials per own query from every peer (x3: forward + the sweep's two)
+            model.reset_bytes()
+            model(torch.from_numpy(q))
+            assert model.bytes_sent["gather"] == B * 1040 * (world - 1)
+            assert model.bytes_sent["exchange"] == B * 4096 * (world - 1) == model.bytes_received["exchange"]
+            assert model.bytes_sent["reduce"] == world * B * 16 * (world - 1)
+        assert np.array_equal(outs[True], outs[False]) and np.array_equal(outs[True, "sweep"], outs[False, "sweep"])
         # beta sweep: one scan, H and G once, every beta from them
         model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5, n_chunks=2)
         model.min_chunk = 2
@@ -145,16 +198,17 @@ def _worker(rank, world, port, N, B, L, H, ret):
         np.testing.assert_allclose(tv.numpy(), rv, atol=1e-7)
         ret[rank] = "ok"
     except Exception as ex:  # noqa: BLE001
-        ret[rank] = f"{type(ex).__name__}: {ex}"
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_forward_gloo(world):
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), 601, 200, 10, 64, ret), nprocs=world, join=True)
-    assert dict(ret) == {r: "ok" for r in range(world)}
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
 
 
 def test_shard_rows_cover():
@@ -253,3 +307,52 @@ def test_two_dimensional_layout_gloo(R):
     ret = mp.Manager().dict()
     mp.spawn(_layout_worker, args=(world, _free_port(), R, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def _subgroup_layout_worker(rank, world, port, ret):
+    """make_layout over a NON-default group: only the sub-group's ranks call it (rank 0 of the job
+    stays out: it could not be made to enter the new_group calls)."""
+    from range_amd.dist import make_layout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sub = dist.new_group(ranks=list(range(1, world)))      # (every rank of the job enters this one)
+        if rank >= 1:
+            N, L, H, B, R = 601, 10, 64, 66, 2
+            group, si, qg = make_layout(R, group=sub)
+            assert (si, qg) == ((rank - 1) % R, (rank - 1) // R) and dist.get_world_size(group) == R
+            locs, vals, keys = synth.make_bank(N, 11)
+            full = O.prep_bank(locs, vals, keys)
+            r0, r1 = shard_rows(N, R, si)
+            w = synth.make_encoder_weights(L, H, 256, 2, 5)
+            model = ShardedRange(OracleShardEngine(w, L, O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1]), r0),
+                                 "RANGE+", 0.5, group=group)
+            q = synth.make_queries(B, seed=500 + rank)
+            err = float(np.abs(model.embed(torch.from_numpy(q)).numpy() - O.forward(q, w, L, full, "RANGE+", 0.5)).max())
+            assert err < 1e-5, err
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layout_over_a_subgroup_of_the_job_gloo():
+    world = 5
+    ret = mp.Manager().dict()
+    mp.spawn(_subgroup_layout_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def test_embed_refuses_a_b_max_below_the_own_count():
+    class _E:            # (never reached)
+        pass
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = ShardedRange(_E(), "RANGE+", 0.5)
+        with pytest.raises(ValueError, match="b_max"):
+            model.embed(torch.zeros((5, 2), dtype=torch.float64), b_max=4)
+    finally:
+        dist.destroy_process_group()

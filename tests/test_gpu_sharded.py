@@ -8,7 +8,9 @@ over gloo (staged through the host, range_amd/dist.py) - ``load_model(..., shard
   C5 shape  the beta sweep {0, .25, .5, .75, 1} over the full bank, 20 000 queries: every beta's sample
             against the oracle, the beta = 0.5 slice against the plain forward;
   drop-in   ``model(coords)`` with the same batch on every rank returns the full batch (B = 1 001, 1);
-            ``save_embeddings`` driven by the sharded model writes the reference's files from rank 0.
+            ``save_embeddings`` driven by the sharded model: every rank embeds its rows, only rank 0 receives
+            results (byte counters) and writes the reference's files - the single-GPU driver's files;
+  pass 1    per chunk with overlapped collectives == unchunked, bit for bit.
 
 What only a real multi-GPU node can add is RCCL itself and the timing."""
 import os
@@ -118,12 +120,55 @@ def _rank(rank, world, port, ck, rbank, tmp, ret):
                 n = bs if i + 1 < n_batches else bs - 37                 # ragged tail (save.py:24-37)
                 yield torch.from_numpy(synth.make_queries(n, seed=900 + i)), torch.arange(n, dtype=torch.float32)
         a = Namespace(embeddings_dir=os.path.join(tmp, "emb"), location_model_name="RANGE+", task_name="t")
+        m.sharded.reset_bytes()
         save_embeddings(a, loader(3, 500), loader(2, 300), m)
         dist.barrier()
+        # every rank embedded ITS rows of every batch and only rank 0 received results: 10 KB per own
+        # query sent by the others (batches of 500, 500, 463 and 300, 263 rows over the ranks), nothing
+        # by rank 0 - an all-gather of the full batch on every rank would move W times that
+        per = sum((n + world - 1) // world for n in (500, 500, 463, 300, 263))
+        assert m.sharded.bytes_sent["results"] == (0 if rank == 0 else per * 10240)
+        assert m.sharded.bytes_received["results"] == ((world - 1) * per * 10240 if rank == 0 else 0)
         z = np.load(os.path.join(tmp, "emb", "RANGE+", "t_train.npz"))
         assert z["embeddings"].shape == (1463, 1280) and z["coords"].shape == (1463, 2) and z["y"].shape == (1463,)
         _sample_check(z["embeddings"][None, :32], z["coords"][:32], obank, w, (0.5,))
-        assert np.load(os.path.join(tmp, "emb", "RANGE+", "t_val.npz"))["embeddings"].shape == (563, 1280)
+        zv = np.load(os.path.join(tmp, "emb", "RANGE+", "t_val.npz"))
+        assert zv["embeddings"].shape == (563, 1280)
+        # a 10 000-query batch: <= 10 000 / W rows (+ 1) of 10 KB leave a rank
+        m.sharded.reset_bytes()
+        big = Namespace(embeddings_dir=os.path.join(tmp, "emb_big"), location_model_name="RANGE+", task_name="b")
+        save_embeddings(big, loader(1, 10_037), loader(1, 101), m)
+        assert m.sharded.bytes_sent["results"] <= (10_000 // world + 1 + 64 // world + 1) * 10240
+        dist.barrier()
+        if rank == 0:
+            # the same files from the single-GPU driver (whole bank on one GPU): coords and y equal, the
+            # e-hat half to float64 rounding, the retrieval half within the float32 split-order rounding
+            m1 = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=rbank, beta=0.5)
+            a1 = Namespace(embeddings_dir=os.path.join(tmp, "emb1"), location_model_name="RANGE+", task_name="t")
+            save_embeddings(a1, loader(3, 500), loader(2, 300), m1)
+            for name, zs in (("t_train.npz", z), ("t_val.npz", zv)):
+                z1 = np.load(os.path.join(tmp, "emb1", "RANGE+", name))
+                assert np.array_equal(z1["coords"], zs["coords"]) and np.array_equal(z1["y"], zs["y"])
+                # (e-hat: the encoder splits its first layer's K by batch size - last-bit differences)
+                assert float(np.abs(z1["embeddings"][:, 1024:] - zs["embeddings"][:, 1024:]).max()) < 1e-13
+                d = np.abs(z1["embeddings"][:, :1024] - zs["embeddings"][:, :1024])
+                assert float(d[:, 2:].max()) < 2e-6 and float(d[:, :2].max()) < 5e-5
+            del m1
+        dist.barrier()
+        # ---- pass 1 per chunk with its collectives under compute == one pass 1 between blocking
+        #      collectives, bit for bit (the same bank splits for every chunk, statistics merged in rank order)
+        xs = x[:4096].contiguous()
+        m.sharded.n_chunks, m.sharded.min_chunk = 4, 256
+        chunked = m.sharded.forward(xs)
+        swc = m.sharded.sweep(xs, (0.0, 1.0))
+        assert len(m.sharded._chunk_bounds(4096)) == 4 and m.engine.kept_queries() == world * 4096
+        m.sharded.pass1_chunked = False
+        plain = m.sharded.forward(xs)
+        swp = m.sharded.sweep(xs, (0.0, 1.0))
+        m.sharded.pass1_chunked = True
+        assert torch.equal(chunked, plain) and torch.equal(swc, swp)
+        ii = np.sort(np.random.default_rng(20 + rank).choice(4096, 64, replace=False))
+        _sample_check(chunked[torch.from_numpy(ii).cuda()].cpu().numpy()[None], q[ii], obank, w, (0.5,))
         ret[rank] = "ok"
     except Exception as ex:  # noqa: BLE001
         import traceback

@@ -13,7 +13,8 @@ query - comes on top; DESIGN.md section 6 prices it).
 --layouts W: the strong mode for every 2-D layout R x Q of W ranks (range_amd.dist.make_layout: the bank
 row-sharded over R ranks, Q = W / R such groups each serving its own queries): a rank holds 100 000 / R
 rows, encodes 10 000 / W queries and scans the 10 000 / Q queries of its group.
-Usage: python tools/shard_emulate.py [--json] [--chunks k] [--layouts W] [N ...]"""
+--unchunked-pass1: one pass 1 over all scanned queries (the schedule before round 4), for A/B.
+Usage: python tools/shard_emulate.py [--json] [--chunks k] [--layouts W] [--unchunked-pass1] [N ...]"""
 import json
 import os
 import sys
@@ -37,6 +38,8 @@ LAYOUTS_W = int(sys.argv[sys.argv.index("--layouts") + 1]) if "--layouts" in sys
 if LAYOUTS_W:
     del sys.argv[sys.argv.index("--layouts"):sys.argv.index("--layouts") + 2]
 worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
+if "--unchunked-pass1" in sys.argv:
+    pass
 base = {}
 # (mode, ranks in total, row shards R): a rank scans R x its own queries against 100 000 / R rows
 cases = [(mode, W, W) for mode in ("strong", "weak") for W in worlds]
@@ -53,19 +56,36 @@ for mode, WT, W in cases:                                       # W = ranks of a
         x = torch.from_numpy(synth.make_queries(B, seed=7)).to(dev)
         e64, e32, xq = eng.encode(x)
         e32_all, xq_all = e32.repeat(W, 1).contiguous(), xq.repeat(W, 1).contiguous()
-        # ShardedRange._chunk_bounds: up to 4 chunks of at least 2048 queries per rank (--chunks k forces k)
-        n_chunks = max(1, min(4, B // 2048)) if W > 1 else 1
+        # ShardedRange._chunk_bounds: 2 chunks from 1 024 queries per rank, 4 from 8 192 (--chunks k forces k)
+        n_chunks = max(1, min(4 if B >= 8192 else 2, B // 512)) if W > 1 else 1
         if FORCE_CHUNKS:
             n_chunks = FORCE_CHUNKS
         cuts = [0] + [((B * c) // n_chunks + 32) // 64 * 64 for c in range(1, n_chunks)] + [B]
 
+        # chunk-major order of the scanned queries (ShardedRange._scan), pass 1 per chunk with the
+        # same bank splits, the shards' statistics merged in rank order (here: W copies of the own)
+        ns1 = eng.p1_splits(W * max(hi - lo for lo, hi in zip(cuts[:-1], cuts[1:])))
+        UNCHUNKED = "--unchunked-pass1" in sys.argv
+
         def step():
             eng.encode(x)
-            st = eng.scan_stats(e32_all, xq_all, 12.0, 40.0, keep_logits=True)
-            outs = []
+            sts = []
+            if UNCHUNKED:
+                st_all = eng.scan_stats(e32_all, xq_all, 12.0, 40.0, keep_logits=True)
             for lo, hi in zip(cuts[:-1], cuts[1:]):
                 first, m = W * lo, W * (hi - lo)
-                part = eng.attend_kept(first, xq_all[first:first + m], 12.0, 40.0, 0.5, st[first:first + m])
+                if UNCHUNKED:
+                    sts.append(st_all[first:first + m])
+                    continue
+                st = eng.scan_stats_at(e32_all[first:first + m], xq_all[first:first + m], 12.0, 40.0,
+                                       first, W * B, n_splits=ns1)
+                if W > 1:      # (its l is 1/W of the group's sum here: the emulation only times the kernel)
+                    st = eng.merge_stats(st.unsqueeze(0).expand(W, m, 4).contiguous())
+                sts.append(st)
+            outs = []
+            for (lo, hi), st in zip(zip(cuts[:-1], cuts[1:]), sts):
+                first, m = W * lo, W * (hi - lo)
+                part = eng.attend_kept(first, xq_all[first:first + m], 12.0, 40.0, 0.5, st)
                 outs.append(eng.finalize(part.reshape(W, hi - lo, 1024), e64[lo:hi].contiguous()))
             return outs
 
