@@ -132,10 +132,17 @@ int32_t range_get_pv_mode(const range_ctx* ctx);
  *   xq32_dev   : (B,4)   float32   (x,y,z,0), the .float() operand of range.py:231
  * Up to 512 queries run as ONE persistent launch whose workgroups wait for each other inside the
  * kernel (bounded: seconds).  Should such a wait ever give up - only when something else holds the
- * GPU's CUs that long - the kernel sets a word of host-mapped memory; the NEXT encoder call on this
- * context (and range_forward_host, which synchronises, before it returns) reports RANGE_ERR_HIP
- * instead of handing out that call's wrong rows.  range_debug_raise_async_error sets the word the
- * way the kernel would (test hook). */
+ * GPU's CUs that long - the rows of THAT call's outputs which could not be finished are written as
+ * NaN (never stale memory), a word of host-mapped memory is set, and the context runs the encoder
+ * as separate launches from then on.  The failure is reported as RANGE_ERR_HIP by the next call that
+ * looks: range_encode / range_forward* / range_topk_stream at entry, range_forward_host /
+ * range_profile_read / range_topk_stream_exact_count before they return (they synchronise), and
+ * range_check_async_error, which a caller invokes behind its own synchronisation (the Python host
+ * does behind every .cpu()).  Reported once; the re-issued call takes the fall-back path.  The
+ * fused top-k (range_topk_stream) follows the same rules with NaN values / index -1. */
+int range_check_async_error(range_ctx* ctx);
+/* Test hook: the NEXT persistent launch on this context (one-launch encoder or fused top-k)
+ * behaves as if its in-launch wait had expired.  `stream` is unused. */
 int range_debug_raise_async_error(range_ctx* ctx, range_stream_t stream);
 int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* ehat64_dev,
                  float* ehat32_dev, float* xq32_dev, range_stream_t stream);

@@ -37,7 +37,7 @@ SYMBOLS = (
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
     "range_set_pv_mode", "range_get_pv_mode", "range_set_keys", "range_debug_raise_async_error",
-    "range_scan_stats_at", "range_p1_splits",
+    "range_scan_stats_at", "range_p1_splits", "range_check_async_error",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
     lib.range_set_bank.argtypes = [vp, vp, vp, vp, i64, i64]
     lib.range_set_keys.argtypes = [vp, vp, i64, i64]
     lib.range_debug_raise_async_error.argtypes = [vp, vp]
+    lib.range_check_async_error.argtypes = [vp]
     lib.range_bank_rows.argtypes = [vp]
     lib.range_bank_rows.restype = i64
     lib.range_encode.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -237,6 +238,17 @@ class HipEngine:
     def pv_mode(self) -> str:
         m = self.lib.range_get_pv_mode(self._h)
         return {v: k for k, v in PV_MODES.items()}[m]
+
+    def check_async_error(self) -> None:
+        """Raise if a persistent launch of an earlier call on this engine gave up waiting for its
+        workgroups (range_hip.h: range_check_async_error).  Costs one read of host memory; meant
+        to be called BEHIND a synchronisation (``.cpu()``, an event, a collective's result on the
+        host) - the failed call's rows are NaN by then and the re-issued call takes the fall-back."""
+        _check(self.lib, self.lib.range_check_async_error(self._h))
+
+    def debug_fail_next_persistent_launch(self) -> None:
+        """Test hook (range_debug_raise_async_error)."""
+        _check(self.lib, self.lib.range_debug_raise_async_error(self._h, None))
 
     # -- helpers -------------------------------------------------------------------------------
     def _stream(self) -> int:

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "async_err.h"
+
 namespace range_hip {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -89,6 +91,7 @@ struct EncArgs {
     // when the context is created, left zero by every launch
     uint32_t* sync;
     uint32_t* err;              // host-mapped word (or null): set when a bounded in-kernel wait gave up
+    int32_t debug_giveup;       // test hook: every in-launch wait behaves as if it had expired
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -698,35 +701,56 @@ __global__ __launch_bounds__(256) void encoder_norm_kernel(EncArgs a) {
 // else's kernels (another process on the same GPU) the launch is only slower, never stuck:
 // workgroups are dispatched in blockIdx order, the producers of phase 1 never wait and leave when
 // done, and from phase 2 on producers and consumers are the same K workgroups, resident by then;
-// a wait that does not end within ENC_SPIN_LIMIT polls (seconds) gives up instead of hanging.
+// a wait that does not end within ENC_SPIN_LIMIT polls (seconds) gives up instead of hanging - and
+// the tile's output rows are then NaN, the context's host-mapped error word is set, and the host
+// takes the separate-launch path from the next call on (range_hip.hip: check_async_error).
 // The counters wrap to zero by themselves: arrivals + one increment per consumer = the wrap limit
 // of the atomic inc.
 constexpr uint32_t ENC_SPIN_LIMIT = 1u << 21;
-// returns false for a workgroup that has no part in the next phase (or whose wait gave up)
-__device__ __forceinline__ bool enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag,
-                                               uint32_t* err) {
+// returns 1 for a workgroup that goes on to the next phase, 0 for one that has no part in it, -1
+// for one whose wait gave up.  A workgroup that gives up does NOT count itself out of the counter
+// it polled: the tile's later phases can then never complete, every workgroup still waiting for
+// them gives up too, and nothing is written over the NaN rows that workgroup 0 of the tile - a
+// consumer of every phase - leaves behind (encoder_tile_kernel).
+__device__ __forceinline__ int enc_phase_sync(uint32_t* ctr, int n_prod, int n_cons, bool consumer, int* flag,
+                                              uint32_t* err, int debug_giveup) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (every wave: its stores have completed)
     __syncthreads();
     if (threadIdx.x == 0) atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));
-    if (!consumer) return false;
+    if (!consumer) return 0;
     if (threadIdx.x == 0) {
         int ok = 1;
         for (uint32_t spins = 0;
              __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)n_prod; ++spins) {
-            if (spins > ENC_SPIN_LIMIT) {
-                // the tile's later phases do not run: say so where the host sees it without a
-                // synchronisation (range_hip.hip: check_async_error)
-                if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = 0;
-                break;
-            }
+            if (spins > ENC_SPIN_LIMIT) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));     // (the last consumer's increment wraps the counter to 0)
+        if (debug_giveup) ok = 0;
+        if (ok) {
+            atomicInc(ctr, (uint32_t)(n_prod + n_cons - 1));     // (the last consumer's increment wraps the counter to 0)
+        } else if (err) {
+            // say so where the host sees it without a synchronisation (range_hip.hip: check_async_error)
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         *flag = ok;
     }
     __syncthreads();
-    return *flag != 0;
+    return *flag != 0 ? 1 : -1;
+}
+
+// what a tile whose in-launch wait gave up hands out: NaN in every output row (one thread per element)
+__device__ __forceinline__ void encoder_poison_tile(const EncArgs& a, int64_t q0) {
+    const double nan64 = __builtin_nan("");
+    const float nan32 = __builtin_nanf("");
+    for (int idx = threadIdx.x; idx < 16 * ENC_EMBED; idx += blockDim.x) {
+        const int64_t q = q0 + idx / ENC_EMBED;
+        if (q >= a.B) break;
+        const int n = idx % ENC_EMBED;
+        a.ehat64[q * ENC_EMBED + n] = nan64;
+        a.ehat32[q * ENC_EMBED + n] = nan32;
+        if (a.eraw64) a.eraw64[q * ENC_EMBED + n] = nan64;
+        if (n < 4) a.xq[q * 4 + n] = nan32;
+    }
 }
 
 template <int NTP, int NWP>
@@ -755,7 +779,17 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // the second layer, but 4 the last one); the others leave after the first layer.
     const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
     const int K = max(max(n_act, a.n_parts2), 4);
-    if (!enc_phase_sync(sync, n_wg, K, b < K, flag, a.err)) return;
+    // a phase hand-off; a workgroup that leaves because its wait gave up: workgroup 0 of the tile (a
+    // consumer of every phase, and the only writer of the results) leaves NaN rows behind
+#define ENC_HANDOFF(ctr, n_prod, n_cons, consumer)                                              \
+    do {                                                                                        \
+        const int go = enc_phase_sync(ctr, n_prod, n_cons, consumer, flag, a.err, a.debug_giveup); \
+        if (go <= 0) {                                                                          \
+            if (go < 0 && b == 0) encoder_poison_tile(a, q0);                                   \
+            return;                                                                             \
+        }                                                                                       \
+    } while (0)
+    ENC_HANDOFF(sync, n_wg, K, b < K);
     ENC_STAMP(2);
     if (b < n_act) {
         const int e = b * (int)blockDim.x + (int)threadIdx.x;
@@ -769,17 +803,18 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     }
     ENC_STAMP(3);
     // ---- second layer on the first n_parts2 workgroups
-    if (!enc_phase_sync(sync + 64, K, K, true, flag, a.err)) return;
+    ENC_HANDOFF(sync + 64, K, K, true);
     ENC_STAMP(4);
     if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, q0, smem, b);
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
-    if (!enc_phase_sync(sync + 128, K, K, true, flag, a.err)) return;
+    ENC_HANDOFF(sync + 128, K, K, true);
     ENC_STAMP(6);
     if (b < 4) encoder_body<4, 4, 1, 4>(a, q0, smem, b);
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
-    if (!enc_phase_sync(sync + 192, K, 1, b == 0, flag, a.err)) return;
+    ENC_HANDOFF(sync + 192, K, 1, b == 0);
+#undef ENC_HANDOFF
     {
         const int64_t q = q0 + (threadIdx.x >> 6);
         if (q < a.B) encoder_norm_query(a, q, threadIdx.x & 63);

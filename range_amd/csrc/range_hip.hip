@@ -89,7 +89,9 @@ struct range_ctx {
     bool topks_force_exact = false;          // RANGE_TOPKS_FORCE_EXACT=1: tests of the fallback
     bool topks_bf16 = true;                  // RANGE_TOPKS_KEYS=f32: stream the float32 keys (no prefilter)
     bool topks_fused = true;                 // RANGE_TOPKS_FUSED=0: the merge as a second launch at every batch size (A/B)
-    DevBuf<uint32_t> ws_topk_sync;           // TOPKS_SYNC_WORDS: arrival counters, done, sticky error, key-norm scratch
+    DevBuf<uint32_t> ws_topk_sync;           // TOPKS_SYNC_WORDS: 8 arrival counters (they only count up), key-norm scratch
+    uint32_t topk_sync_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the counters read when the next fused launch starts
+    bool debug_giveup_next = false;          // range_debug_raise_async_error: the next persistent launch gives up
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
     bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 32 queries take the two-pass kernels too (A/B)
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
@@ -98,8 +100,9 @@ struct range_ctx {
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
     DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
     DevBuf<uint32_t> ws_enc_sync;   // encoder_tile_kernel: 4 phase counters, 64 words apart
-    // a word of host memory the kernels can write (hipHostMallocMapped): set by a persistent kernel
-    // whose bounded wait for other workgroups gave up; read - without synchronising - by the next call
+    // words of host memory the kernels can write (hipHostMallocMapped; async_err.h): set by a persistent
+    // kernel whose bounded wait for other workgroups gave up; read - without synchronising - by the
+    // next call and behind every synchronising exit (check_async_error)
     uint32_t* h_async_err = nullptr;
     uint32_t* d_async_err = nullptr;
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
@@ -190,7 +193,9 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         a.h1a = c->ws_h1a.p;
         a.e3 = c->ws_e3.p;
         a.sync = c->ws_enc_sync.p;
-        a.err = c->d_async_err;
+        a.err = c->d_async_err ? c->d_async_err + RANGE_ASYNC_WORD_ENCODER : nullptr;
+        a.debug_giveup = c->debug_giveup_next ? 1 : 0;
+        c->debug_giveup_next = false;
         a.n_parts2 = a.H / 64;
         a.part2_cols = 64;
         a.rest_from = 1;
@@ -651,8 +656,9 @@ static int upload_keys(range_ctx* c, const float* keys, int64_t n_rows, int64_t 
     if (!c->ws_topk_sync.p) {
         HIP_TRY(c->ws_topk_sync.ensure(TOPKS_SYNC_WORDS));
         HIP_TRY(hipMemset(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4));
+        std::memset(c->topk_sync_base, 0, sizeof c->topk_sync_base);
     }
-    uint32_t* scratch = c->ws_topk_sync.p + TOPKS_SYNC_ERROR + 1;
+    uint32_t* scratch = c->ws_topk_sync.p + TOPKS_SYNC_SCRATCH;
     HIP_TRY(hipMemset(scratch, 0, 4));
     hipLaunchKernelGGL(key_norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, 0, c->d_keys.p, n_rows, scratch);
     HIP_TRY(hipGetLastError());
@@ -736,30 +742,40 @@ int range_set_pv_mode(range_ctx* c, int32_t mode) {
 }
 int32_t range_get_pv_mode(const range_ctx* c) { return c ? c->pv_mode : -1; }
 
-// A persistent kernel of an EARLIER call that gave up waiting for its other workgroups (possible only
-// when something else holds the GPU's CUs for seconds) has left wrong results behind: the word it
-// set in host memory is read here, in front of the next encoder call and behind every synchronous
-// one, without touching the stream.
+// A persistent kernel that gave up waiting for its other workgroups (possible only when something
+// else holds the GPU's CUs for seconds) has written NaN rows (encoder) / NaN values and -1 indices
+// (top-k) for what it could not finish, and set a word of host memory.  That word is read here - in
+// front of the next encoder / top-k call and behind every synchronising exit, without touching the
+// stream - and the context takes the separate-launch form of that kernel from then on: co-residency
+// of a persistent grid is a precondition the library cannot check, so after one failure it stops
+// relying on it (the same branch RANGE_ENC_FUSED=0 / RANGE_TOPKS_FUSED=0 select).
 static int check_async_error(range_ctx* c) {
-    if (c->h_async_err && *(volatile uint32_t*)c->h_async_err) {
-        *(volatile uint32_t*)c->h_async_err = 0;
-        return fail(RANGE_ERR_HIP, "a persistent encoder launch of an earlier call gave up waiting for its workgroups "
-                                   "(is another process holding the GPU?); the results of that call are invalid");
-    }
-    return RANGE_OK;
+    if (!c->h_async_err) return RANGE_OK;
+    volatile uint32_t* w = c->h_async_err;
+    const bool enc = w[RANGE_ASYNC_WORD_ENCODER] != 0, topk = w[RANGE_ASYNC_WORD_TOPK] != 0;
+    if (!enc && !topk) return RANGE_OK;
+    w[RANGE_ASYNC_WORD_ENCODER] = 0;
+    w[RANGE_ASYNC_WORD_TOPK] = 0;
+    if (enc) c->enc_fused = false;
+    if (topk) c->topks_fused = false;
+    return fail(RANGE_ERR_HIP, "a persistent %s launch of an earlier call gave up waiting for its workgroups (is another "
+                               "process holding the GPU?); the rows it could not finish were written as NaN%s, and this "
+                               "context runs that step as separate launches from now on: re-issue the call",
+                enc && topk ? "encoder and a top-k" : enc ? "encoder" : "top-k", topk ? " / index -1" : "");
 }
 
-__global__ void raise_async_error_kernel(uint32_t* err) {
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+int range_check_async_error(range_ctx* c) {
+    if (!c) return fail(RANGE_ERR_INVALID, "null argument");
+    return check_async_error(c);
 }
-// test hook: what a persistent kernel does when its bounded wait gives up (tests/test_gpu_round2.py)
-int range_debug_raise_async_error(range_ctx* c, range_stream_t stream) {
+
+// test hook: the NEXT persistent launch of this context (the one-launch encoder of up to 512 queries,
+// or the fused top-k) behaves as if its bounded in-launch wait had expired - the real give-up path:
+// NaN / -1 outputs, the host-mapped word, the fall-back (tests/test_gpu_round2.py)
+int range_debug_raise_async_error(range_ctx* c, range_stream_t) {
     if (!c) return fail(RANGE_ERR_INVALID, "null argument");
     if (!c->d_async_err) return fail(RANGE_ERR_STATE, "no host-mapped error word in this context");
-    DeviceGuard g(c->device);
-    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
-    hipLaunchKernelGGL(raise_async_error_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->d_async_err);
-    HIP_TRY(hipGetLastError());
+    c->debug_giveup_next = true;
     return RANGE_OK;
 }
 
@@ -772,7 +788,6 @@ static int encode_impl(range_ctx* c, const double* lonlat, int64_t B, double* eh
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     EncArgs a = c->enc;
-    a.err = c->d_async_err;
     a.lonlat = lonlat;
     a.ehat64 = ehat64;
     a.eraw64 = eraw64;
@@ -1019,6 +1034,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     if (!c || !ehat32 || !topk_val || !topk_idx) return fail(RANGE_ERR_INVALID, "null argument");
     if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
     if (B <= 0 || k <= 0 || k > MAX_TOPK) return fail(RANGE_ERR_INVALID, "bad B or k");
+    if (int rc0 = check_async_error(c)) return rc0;
     DeviceGuard g(c->device);
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1048,6 +1064,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     if (!c->ws_topk_sync.p) {
         HIP_TRY(c->ws_topk_sync.ensure(TOPKS_SYNC_WORDS));
         HIP_TRY(hipMemsetAsync(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4, s));
+        std::memset(c->topk_sync_base, 0, sizeof c->topk_sync_base);
     }
     TopkStreamArgs a{};
     a.keys = c->d_keys.p;
@@ -1060,6 +1077,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     a.n_groups = n_groups;
     a.keys_bf16 = c->d_keys_bf16.p;
     a.sync = c->ws_topk_sync.p;
+    a.err = c->d_async_err ? c->d_async_err + RANGE_ASYNC_WORD_TOPK : nullptr;
     a.fused = fused ? 1 : 0;
     a.k = k;
     a.row_offset = c->row_offset;
@@ -1100,6 +1118,8 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         HIP_TRY(hipEventRecord(ev0, s));
     }
     for (int rep = 0; rep < std::max(1, repeats); ++rep) {
+        for (int x = 0; x < 8; ++x) a.sync_base[x] = c->topk_sync_base[x];
+        a.debug_giveup = fused && c->debug_giveup_next ? 1 : 0;
         if (bf16) {
             if (G == 1) RANGE_TOPKS_LAUNCH_BF16(1);
             else RANGE_TOPKS_LAUNCH_BF16(2);
@@ -1108,6 +1128,11 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
             else RANGE_TOPKS_LAUNCH(2);
         }
         HIP_TRY(hipGetLastError());
+        if (fused) {
+            // every workgroup of the launch takes one ticket of its shard (blockIdx % 8)
+            for (int x = 0; x < 8; ++x) c->topk_sync_base[x] += (uint32_t)((n_wg - x + 7) >> 3);
+            c->debug_giveup_next = false;
+        }
         if (!fused) {
             rc = set_dyn_lds(topk_merge_kernel<TOPKS_WL>, TOPKM_LDS_BYTES);
             if (rc) return rc;
@@ -1215,18 +1240,7 @@ int range_topk_stream_exact_count(range_ctx* c, int64_t* count) {
     HIP_TRY(hipMemcpy(v, c->ws_exact_count.p, sizeof v, hipMemcpyDeviceToHost));
     *count = v[0];
     if (std::getenv("RANGE_TOPKS_DIAG")) std::fprintf(stderr, "range_topk_stream: %d candidates ranked so far\n", v[1]);
-    if (c->ws_topk_sync.p) {
-        uint32_t sy = 0;
-        HIP_TRY(hipMemcpy(&sy, c->ws_topk_sync.p + TOPKS_SYNC_ERROR, sizeof sy, hipMemcpyDeviceToHost));
-        if (sy != 0) {
-            // a merging workgroup of range_topk_stream gave up waiting for the others (the grid was
-            // not resident as a whole): its query's results were marked invalid (index -1, NaN)
-            HIP_TRY(hipMemset(c->ws_topk_sync.p, 0, TOPKS_SYNC_WORDS * 4));
-            return fail(RANGE_ERR_HIP, "range_topk_stream: a merging workgroup timed out waiting for the "
-                        "stream workgroups (results of that call carry index -1 / NaN)");
-        }
-    }
-    return RANGE_OK;
+    return check_async_error(c);     // (a merging workgroup of an earlier fused call that gave up)
 }
 
 int range_merge_stats(range_ctx* c, const float* parts, int32_t n_parts, int64_t B, float* out,
@@ -1593,8 +1607,14 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
         for (auto v : tail) rest += v;
         if (rest < B) {
             int64_t at = B - rest;
-            // (cuts rounded UP to a query tile: the last part is at most its nominal size, whole slabs)
-            for (auto v : tail) { cuts.push_back((at + QTILE - 1) / QTILE * QTILE); at += v; }
+            // (cuts rounded UP to a query tile: the last part is at most its nominal size, whole slabs;
+            // never past the batch and never backwards, whatever RANGE_HOST_PARTS holds)
+            for (auto v : tail) {
+                const int64_t cut = std::min<int64_t>(B, (at + QTILE - 1) / QTILE * QTILE);
+                if (cut > cuts.back()) cuts.push_back(cut);
+                at += v;
+            }
+            if (cuts.back() == B) cuts.pop_back();
         }
     }
     cuts.push_back(B);
@@ -1704,7 +1724,7 @@ int range_profile_read(range_ctx* c, int32_t which, double* total_ms, int32_t* l
     }
     *total_ms = sum;
     *launches = (int32_t)c->prof[which].size();
-    return RANGE_OK;
+    return check_async_error(c);     // (the events above synchronised: a give-up of the profiled calls is known now)
 }
 
 int range_last_attend_geometry(const range_ctx* c, int32_t* n_query_tiles, int32_t* n_splits) {

@@ -38,6 +38,7 @@
 // Dot products are the same single dependent MFMA chain, in the same k order, as in the scan
 // kernels of attend_kernels.h: every kernel that forms a similarity gets the same float.
 #pragma once
+#include "async_err.h"
 #include "attend_kernels.h"
 
 namespace range_hip {
@@ -55,8 +56,11 @@ struct TopkStreamArgs {
     unsigned long long* stamps; // RANGE_EXP_TS_STAMPS builds: 8 s_memrealtime stamps per wave
     const void* keys_bf16;      // prefilter form: (n_tiles, 8 chunks, 64 lanes, 8) bf16, see keyfrag_kernel
     // ---- the merge (topk_merge_query), as the tail of the same launch when `fused`
-    uint32_t* sync;             // TOPKS_SYNC_WORDS words (topks_tail): 8 arrival counters, `done`, a sticky error
-                                // word; zeroed by the host once, left zero by every launch
+    uint32_t* sync;             // TOPKS_SYNC_WORDS words (topks_tail): 8 arrival counters that only ever count up
+    uint32_t sync_base[8];      // what the counters read when this launch starts (the host adds every fused
+                                // launch's arrivals: nothing is zeroed, nothing a give-up could leave behind)
+    uint32_t* err;              // host-mapped word (or null): set when a merging workgroup's bounded wait gave up
+    int32_t debug_giveup;       // test hook: the merging workgroups behave as if their wait had expired
     int32_t fused;              // 1: the last min(B, n_wg) workgroups to arrive merge one query each
     int32_t k;
     int64_t row_offset;
@@ -327,16 +331,17 @@ __device__ void topk_merge_prefetch(char* lds, int64_t q, const TopkStreamArgs& 
 //  * all workgroups of the grid are resident (one per CU, grid <= CUs), every one takes its
 //    ticket BEFORE it may wait, and those that do not merge exit: the wait ends.  The spin is
 //    bounded all the same; a workgroup that gives up marks its query's results invalid
-//    (index -1, NaN) and sets the sticky error word, which range_topk_stream_exact_count reports.
-//  * the counters are zero again when the launch ends: a merging workgroup increments `done`
-//    (atomic inc, wrapping to 0 at the number of mergers) once its wait is over - the value
-//    comes back while it merges - and the one that was last to do so (nobody polls any more)
-//    zeroes the shards.
+//    (index -1, NaN) and sets the context's host-mapped error word: the host reports it at
+//    its next entry or synchronising exit and runs the merge as a second launch from then on.
+//  * the counters only ever count up: the host knows what they read when a launch starts
+//    (a.sync_base: the sum of all earlier fused launches' arrivals, modulo 2^32) and tickets and
+//    waits are differences to that base.  Nothing is zeroed - neither by the host in front of a
+//    launch nor by the last workgroup to leave - so a workgroup that gave up leaves nothing behind
+//    that a later launch could trip over (every workgroup of its launch still took its ticket).
 //  * a merging workgroup loads its query (topk_merge_prefetch) before it waits.
 constexpr int TOPKS_SYNC_STRIDE = 64;                          // words between shard counters (256 B)
-constexpr int TOPKS_SYNC_DONE = 8 * TOPKS_SYNC_STRIDE;         // word index of `done`
-constexpr int TOPKS_SYNC_ERROR = TOPKS_SYNC_DONE + 1;          // sticky error
-constexpr int TOPKS_SYNC_WORDS = TOPKS_SYNC_DONE + 16;         // (+ host scratch: the key-norm reduction)
+constexpr int TOPKS_SYNC_SCRATCH = 8 * TOPKS_SYNC_STRIDE;      // host scratch behind the counters (the key-norm reduction)
+constexpr int TOPKS_SYNC_WORDS = TOPKS_SYNC_SCRATCH + 16;
 __device__ __forceinline__ void topks_tail(const TopkStreamArgs& a, char* smem) {
     RANGE_TT_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // list stores done; the clamped prefetches past the end landed
@@ -349,27 +354,30 @@ __device__ __forceinline__ void topks_tail(const TopkStreamArgs& a, char* smem) 
     const int shard = (int)(blockIdx.x & 7);
     const int shard_size = (n_wg - shard + 7) >> 3, shard_workers = (n_workers - shard + 7) >> 3;
     if (threadIdx.x == 0)
-        ctl[0] = (int)__hip_atomic_fetch_add(a.sync + TOPKS_SYNC_STRIDE * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[0] = (int)(__hip_atomic_fetch_add(a.sync + TOPKS_SYNC_STRIDE * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                       a.sync_base[shard]);
     __syncthreads();
     RANGE_TT_STAMP(2);
     const int local = ctl[0] - (shard_size - shard_workers);
     if (local < 0) return;
     const int64_t q = shard + 8 * local;
+    if (q >= a.B) return;                  // (cannot happen while host and counters agree; never index past the batch)
     topk_merge_prefetch<TOPKS_WL>(smem, q, a);
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const uint32_t need = lane < 8 ? (uint32_t)((n_wg - lane + 7) >> 3) : 0u;
+        const uint32_t base = lane < 8 ? a.sync_base[lane] : 0u;
         int ok = 1;
         for (uint32_t spins = 0;; ++spins) {
-            const uint32_t v = lane < 8 ? ld_agent(a.sync + TOPKS_SYNC_STRIDE * lane) : 0u;
+            const uint32_t v = lane < 8 ? ld_agent(a.sync + TOPKS_SYNC_STRIDE * lane) - base : 0u;
             if (__ballot(v >= need) == ~0ull) break;
             if (spins > TOPKS_SPIN_LIMIT) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (a.debug_giveup) ok = 0;
         if (lane == 0) {
             ctl[1] = ok;
-            if (ok) ctl[2] = (int)atomicInc(a.sync + TOPKS_SYNC_DONE, (uint32_t)(n_workers - 1));
-            else st_agent(a.sync + TOPKS_SYNC_ERROR, 1u);
+            if (!ok && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     __syncthreads();
@@ -386,7 +394,6 @@ __device__ __forceinline__ void topks_tail(const TopkStreamArgs& a, char* smem) 
 #endif
     topk_merge_query<TOPKS_WL>(smem, q, a, n_wg);
     RANGE_TT_STAMP(15);
-    if (threadIdx.x < 8 && ctl[2] == n_workers - 1) st_agent(a.sync + TOPKS_SYNC_STRIDE * threadIdx.x, 0u);
 #ifdef RANGE_EXP_TS_STAMPS   // shader clocks the merge took (slot 14): against stamps 3 -> 15 it gives the clock rate
     if (threadIdx.x == 0 && a.stamps)
         a.stamps[(size_t)gridDim.x * 4 * 8 + (size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime() - clk0;

@@ -97,10 +97,9 @@ class LocationEncoder(nn.Module):
     #: queries per engine call; bounds the per-call workspace (split slabs of chunk x 4 KB)
     chunk_size = 16384
     #: topk(): batches up to this size go through the HBM-streaming kernel in one call (bf16-key
-    #: prefilter + float32 re-rank: 26 us for 16 queries on range_db_large, 38 us for 64, 0.11 ms for
-    #: 256, 0.80 ms for 2 048, 4.0 ms for 10 000 - faster than pass 1 + a selection over its kept
-    #: logits at every size, 0.16 ms / 1.09 ms / 4.9 ms for up to 128 / 2 048 / 10 000 queries;
-    #: tools/topk_total_time.py); larger batches in chunks of this size
+    #: prefilter + float32 re-rank; one launch up to 256 queries: ~20 us for 16 queries on
+    #: range_db_large, ~41 us for 64 (BENCH_r03.json roofline_scan) - faster than pass 1 + a selection
+    #: over its kept logits at every size, tools/topk_total_time.py); larger batches in chunks of this size
     topk_stream_max = 16384
 
     def __init__(self, args):
@@ -228,7 +227,14 @@ class LocationEncoder(nn.Module):
                 G = eng.attend(e32, xq, TEMP_RANGE_PLUS, TEMP_GEO, 0.0, st)
             for j, b in enumerate(betas):
                 out[j, i:i + e64.shape[0]] = eng.finalize(eng.blend(G, H, b), e64)
-        return out if return_device else out.cpu().numpy()
+        return out if return_device else self._to_host(out)
+
+    def _to_host(self, t: torch.Tensor) -> np.ndarray:
+        """``.cpu()`` synchronises: a persistent launch of this call that gave up (NaN rows) is known
+        now - report it instead of handing the rows out (range_hip.h: range_check_async_error)."""
+        h = t.cpu().numpy()
+        self.engine.check_async_error()
+        return h
 
     @torch.no_grad()
     def topk(self, coords, k: int = 16):
@@ -350,13 +356,13 @@ class ShardedLocationEncoder(nn.Module):
         x = self._coords(coords)
         if local:
             out = self.sharded.embed(x)
-            return out if return_device else out.cpu().numpy()
+            return out if return_device else self._to_host(out)
         B = x.shape[0]
         lo, hi = self._own_rows(B)
         full = self._gather_rows(self.sharded.embed(x[lo:hi]), B)
         if return_device:
             return full.to(self.engine.device)
-        return full.cpu().numpy()                                        # range.py:240: a host ndarray
+        return self._to_host(full)                                       # range.py:240: a host ndarray
 
     @torch.no_grad()
     def sweep(self, coords, betas, return_device: bool = False, local: bool = False):
@@ -366,12 +372,18 @@ class ShardedLocationEncoder(nn.Module):
         x = self._coords(coords)
         if local:
             out = self.sharded.embed_sweep(x, betas)
-            return out if return_device else out.cpu().numpy()
+            return out if return_device else self._to_host(out)
         B = x.shape[0]
         lo, hi = self._own_rows(B)
         own = self.sharded.embed_sweep(x[lo:hi], betas)                  # (nb, b_own, 1280)
         full = self._gather_rows(own.permute(1, 0, 2).contiguous(), B).permute(1, 0, 2).contiguous()
-        return full.to(self.engine.device) if return_device else full.cpu().numpy()
+        return full.to(self.engine.device) if return_device else self._to_host(full)
+
+    def _to_host(self, t: torch.Tensor) -> np.ndarray:
+        """``.cpu()`` synchronises: a persistent launch of this rank that gave up is known now."""
+        h = t.cpu().numpy()
+        self.engine.check_async_error()
+        return h
 
     @torch.no_grad()
     def topk(self, coords, k: int = 16, local: bool = False):

@@ -101,6 +101,7 @@ class EmbeddingPipeline:
 
     def _collect(self, slot: int, n: int) -> np.ndarray:
         self._copied[slot].synchronize()
+        self.engine.check_async_error()       # (a persistent launch of this batch that gave up: NaN rows, known now)
         # a fresh array per batch (the reference's contract); its first-touch page faults are
         # spread over the library's copy threads (one thread takes 12 ms per 100 MB)
         src = self._pinned[slot][:n].numpy()
@@ -197,6 +198,7 @@ class ShardedEmbeddingPipeline:
         W = self.world
         if not self.staged:
             self._copied[slot].synchronize()       # (every rank: its send buffer is free again)
+        self.model.engine.check_async_error()
         if self.rank != 0:
             return None
         out = POOL.take(n, 1280)

@@ -408,27 +408,87 @@ def test_one_tile_encoder_over_widths(L, H):
         np.testing.assert_allclose(xq.cpu().numpy()[:, :3], O.query_xyz(q), rtol=0, atol=1.2e-7)
 
 
-def test_a_given_up_in_kernel_wait_is_reported_by_the_next_call():
-    """The persistent encoder's waits between workgroups are bounded; one that gives up sets a word
-    of host-mapped memory (include/range_hip.h at range_encode).  The test hook sets the word the
-    way the kernel would: the next encoder call refuses with RANGE_ERR_HIP without touching the
-    stream, the numpy contract refuses before it hands out rows, and the context works again after."""
-    L, H = 10, 64
+def test_a_given_up_in_kernel_wait_poisons_that_call_and_falls_back():
+    """The persistent launches' waits between workgroups are bounded; one that gives up (test hook:
+    the NEXT persistent launch behaves as if its wait had expired - the kernel's real give-up path)
+    (i) leaves NaN in THAT call's output rows (never stale memory), (ii) is reported by the next look
+    - entry of the next call, the synchronous numpy contract before it returns, check_async_error
+    behind a caller's own synchronisation - and (iii) switches the context to the separate-launch
+    path: the same call re-issued succeeds and equals the oracle (include/range_hip.h at range_encode)."""
+    L, H, N = 20, 256, 500          # (a shape whose small batches take the one-launch encoder)
     w, ws, bs = _weights(L, H, 2, 5)
     eng = _native.HipEngine("cuda:0")
     eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
-    bank = prepare_bank(*synth.make_bank(500, 3))
+    locs, vals, keys = synth.make_bank(N, 3)
+    bank = prepare_bank(locs, vals, keys)
+    obank = O.prep_bank(locs, vals, keys)
     eng.set_bank(bank.keys, bank.values, bank.xyz)
-    x = torch.from_numpy(synth.make_queries(16, seed=1)).cuda()
+    q = synth.make_queries(40, seed=1)
+    x = torch.from_numpy(q).cuda()
+    ref = O.forward(q, w, L, obank, "RANGE+", 0.5)
     good = eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5).cpu().numpy()
-    _native._check(eng.lib, eng.lib.range_debug_raise_async_error(eng._h, eng._stream()))
+    np.testing.assert_allclose(good, ref, rtol=0, atol=2e-5)
+    eng.check_async_error()                                  # nothing to report
+    # ---- the device-resident path: the failed call returns OK (nothing has synchronised yet) ...
+    eng.debug_fail_next_persistent_launch()
+    e64, e32, xq = eng.encode(x)
     torch.cuda.synchronize()
+    # ... but every row it could not finish is NaN, in every output
+    assert bool(torch.isnan(e64).all()) and bool(torch.isnan(e32).all()) and bool(torch.isnan(xq).all())
     with pytest.raises(_native.RangeNativeError, match="gave up waiting"):
-        eng.encode(x)
-    assert np.array_equal(eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5).cpu().numpy(), good)   # reported once, then clear
-    # raised while a synchronous call is in flight: that call itself refuses
-    _native._check(eng.lib, eng.lib.range_debug_raise_async_error(eng._h, eng._stream()))
+        eng.check_async_error()
+    eng.check_async_error()                                  # reported once
+    # the same call re-issued: the separate-launch path from now on, the oracle's rows
+    e64b, _, _ = eng.encode(x)
+    np.testing.assert_allclose(e64b.cpu().numpy(), ref[:, 1024:], rtol=0, atol=2e-12)
+    np.testing.assert_allclose(eng.forward(x, _native.MODEL_RANGE_PLUS, 0.5).cpu().numpy(), ref, rtol=0, atol=2e-5)
+    # ---- the fused top-k tail: NaN values / index -1 for that call, reported, then the two-launch form
+    eng2 = _native.HipEngine("cuda:0")
+    eng2.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    eng2.set_bank(bank.keys, bank.values, bank.xyz)
+    _, e32g, _ = eng2.encode(x)
+    e32g = e32g[:8].contiguous()                             # (one query per stream workgroup: the fused form; 500 rows = 8 workgroups)
+    tv0, ti0 = eng2.topk_stream(e32g, 8)
+    rv, ri = O.topk64(O.logits64(ref[:8, 1024:], q[:8], obank)[0], 8)
+    assert np.array_equal(ti0.cpu().numpy(), ri)
+    eng2.debug_fail_next_persistent_launch()
+    tv, ti = eng2.topk_stream(e32g, 8)
     torch.cuda.synchronize()
+    assert bool(torch.isnan(tv).all()) and bool((ti == -1).all())
+    with pytest.raises(_native.RangeNativeError, match="top-k launch"):
+        eng2.topk_stream(e32g, 8)                            # entry of the next call
+    for _ in range(3):                                       # the fall-back, and the counters of later calls are sound
+        tv2, ti2 = eng2.topk_stream(e32g, 8)
+        assert torch.equal(ti2, ti0) and torch.equal(tv2, tv0)
+    # ---- the numpy contract: the call in flight refuses itself before handing out rows
+    eng3 = _native.HipEngine("cuda:0")
+    eng3.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    eng3.set_bank(bank.keys, bank.values, bank.xyz)
+    eng3.debug_fail_next_persistent_launch()
     with pytest.raises(_native.RangeNativeError, match="gave up waiting"):
-        eng.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5)
-    assert np.array_equal(eng.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5), good)
+        eng3.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5)
+    np.testing.assert_allclose(eng3.forward_host(x, _native.MODEL_RANGE_PLUS, 0.5), ref, rtol=0, atol=2e-5)
+
+
+def test_fused_topk_counters_survive_many_calls_and_batch_sizes():
+    """The fused tail's arrival counters only count up and the host tracks their base: calls of
+    different batch sizes (different numbers of merging workgroups), back to back, never disagree
+    with the two-launch form."""
+    rng = np.random.default_rng(5)
+    keys = rng.standard_normal((20011, 256)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_keys(keys)
+    os.environ["RANGE_TOPKS_FUSED"] = "0"
+    try:
+        ref_eng = _native.HipEngine("cuda:0")
+    finally:
+        os.environ.pop("RANGE_TOPKS_FUSED", None)
+    ref_eng.set_keys(keys)
+    for i, B in enumerate((1, 16, 7, 64, 255, 3, 33, 256, 16, 16, 16, 100)):
+        e = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)).cuda()
+        e = torch.nn.functional.normalize(e, dim=1).contiguous()
+        tv, ti = eng.topk_stream(e, 16)
+        rv, ri = ref_eng.topk_stream(e, 16)
+        assert torch.equal(ti, ri) and torch.equal(tv, rv), (i, B)
+    eng.check_async_error()
