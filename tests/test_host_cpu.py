@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "range_hip.h")).read()
-    declared = set(re.findall(r"\b(range_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(range_[a-z0-9_]+)\s*\(", header))
     declared -= {"range_ctx", "range_stream_t"}
     assert declared == set(_native.SYMBOLS)
     lib = _native.load_library()
