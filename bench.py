@@ -600,6 +600,10 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
              float32 key bytes / time) is given beside it and is not a roofline fraction.
       time per call: 20 calls enqueued back to back between ONE pair of HIP events on the launch
              stream, mean of 3 such measurements.
+      frac_of_copy = plain_read_us / us_per_call: ``plain_read_us`` is a kernel that does nothing but
+             READ the same bytes in one launch (range_stream_read_timed: 16-byte non-temporal loads,
+             32 KB contiguous per workgroup and step), timed the same way - what a launch of that size
+             can reach on this chip at all (6.6 TB/s from DRAM, 7 TB/s out of the Infinity Cache).
 
     Two banks: this run's bank (range_db_large, N = 100 000: its 51 MB bf16 copy stays in the 256 MB
     Infinity Cache between back-to-back calls - ``resident: infinity_cache``) and a keys-only bank
@@ -641,6 +645,8 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
                 groups = (nq + 15) // 16
                 per_pass = 1 if groups <= 1 else 2        # range_topk_stream's choice (range_hip.hip)
                 passes = (groups + per_pass - 1) // per_pass
+                # the same-launch ceiling: a plain kernel that only READS the same bytes, timed the same way
+                copy_us = sum(e.stream_read_timed(keys_mode == "f32", passes, 20) for _ in range(3)) / 3.0
                 ref_bytes = passes * n_rows * KEY_ROW_BYTES
                 streamed = ref_bytes // 2 if keys_mode == "bf16" else ref_bytes
                 kname = "topk_stream_bf16_kernel" if keys_mode == "bf16" else "topk_stream_kernel"
@@ -650,6 +656,8 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
                             "us_source": "20 back-to-back calls between one HIP event pair, mean of 3",
                             "streamed_TBps": streamed / (us * 1e-6) / 1e12, "peak_TBps": PEAK_HBM_GBS / 1e3,
                             "frac": streamed / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                            "plain_read_us": copy_us, "plain_read_TBps": streamed / (copy_us * 1e-6) / 1e12,
+                            "frac_of_copy": copy_us / us,
                             "reference_format_TBps": ref_bytes / (us * 1e-6) / 1e12,
                             "product_path": keys_mode == "bf16",
                             "exact_fallback_queries": e.topk_stream_exact_count()})

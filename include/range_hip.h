@@ -247,6 +247,14 @@ int range_topk_stream_timed(range_ctx* ctx, const float* ehat32_dev, int64_t B, 
                             float* topk_val_dev, int64_t* topk_idx_dev, int32_t repeats,
                             float* avg_us, range_stream_t stream);
 
+/* Bench harness: the ceiling of range_topk_stream's stream - a plain kernel that reads, in ONE
+ * launch, the bytes a call streams (`passes` times the bf16 copy of the keys, or the float32 keys when
+ * f32_keys != 0) and does nothing else; `repeats` (>= 2) launches back to back between one pair of
+ * HIP events, *avg_us = time per launch.  bench.py reports a call's time against it (frac_of_copy).
+ * Synchronises with the stream. */
+int range_stream_read_timed(range_ctx* ctx, int32_t f32_keys, int32_t passes, int32_t repeats,
+                            float* avg_us, range_stream_t stream);
+
 /* Exact merge of per-shard statistics (row-sharded bank): parts_dev is (n_parts,B,4) as written
  * by range_scan_stats on each shard (e.g. after an all-gather); out_dev is (B,4). */
 int range_merge_stats(range_ctx* ctx, const float* parts_dev, int32_t n_parts, int64_t B,

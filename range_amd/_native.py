@@ -37,7 +37,7 @@ SYMBOLS = (
     "range_coord_features", "range_attend_kept", "range_kept_queries", "range_forward_host",
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
     "range_set_pv_mode", "range_get_pv_mode", "range_set_keys", "range_debug_raise_async_error",
-    "range_scan_stats_at", "range_p1_splits", "range_check_async_error",
+    "range_scan_stats_at", "range_p1_splits", "range_check_async_error", "range_stream_read_timed",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.range_topk_stream_exact_count.argtypes = [vp, C.POINTER(i64)]
     lib.range_topk_stream_timed.argtypes = [vp, vp, i64, i32, vp, vp, i32, C.POINTER(f32), vp]
+    lib.range_stream_read_timed.argtypes = [vp, i32, i32, i32, C.POINTER(f32), vp]
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
     lib.range_set_pv_mode.argtypes = [vp, i32]
     lib.range_get_pv_mode.argtypes = [vp]
@@ -381,6 +382,14 @@ class HipEngine:
                                                           ti.data_ptr(), repeats, C.byref(us),
                                                           self._stream()))
         return tv, ti, us.value
+
+    def stream_read_timed(self, f32_keys: bool = False, passes: int = 1, repeats: int = 20) -> float:
+        """Microseconds per launch of a plain streaming read of the bytes ``topk_stream`` streams
+        (``passes`` x the bf16 copy of the keys, or the float32 keys): its same-launch ceiling."""
+        us = C.c_float()
+        _check(self.lib, self.lib.range_stream_read_timed(self._h, int(bool(f32_keys)), passes, repeats,
+                                                          C.byref(us), self._stream()))
+        return us.value
 
     def topk_stream_exact_count(self) -> int:
         """Queries topk_stream recomputed by brute force (its short per-lane lists could have

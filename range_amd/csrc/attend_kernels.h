@@ -532,8 +532,33 @@ struct KeyList {                       // sorted descending; 0 = empty slot
     }
 };
 
+// The value lane ^ 16 / lane ^ 32 holds, through gfx950's row-swap instructions instead of the LDS
+// crossbar (ds_bpermute: ~120 cycles a round trip, and a wave alone on its SIMD has nothing to put
+// into that time): v_permlane16_swap swaps the odd 16-lane rows of its first operand with the even
+// rows of the second, v_permlane32_swap the upper half of the first with the lower half of the
+// second.  With both operands = x the partner's value ends up in the second operand for lanes of
+// even rows / the lower half and in the first for the others: one move, one swap, one select.
+typedef uint32_t range_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lane_xor16(uint32_t x) {
+    const range_u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (__lane_id() & 16) ? r[0] : r[1];
+}
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t x) {
+    const range_u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (__lane_id() & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ float lane_xor16(float x) { return __uint_as_float(lane_xor16(__float_as_uint(x))); }
+__device__ __forceinline__ float lane_xor32(float x) { return __uint_as_float(lane_xor32(__float_as_uint(x))); }
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x, int m) {
     const uint32_t lo = __shfl_xor((uint32_t)x, m), hi = __shfl_xor((uint32_t)(x >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int M>
+__device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long x) {
+    static_assert(M == 16 || M == 32, "row swaps exist for lane ^ 16 and lane ^ 32");
+    const uint32_t lo = M == 16 ? lane_xor16((uint32_t)x) : lane_xor32((uint32_t)x);
+    const uint32_t hi = M == 16 ? lane_xor16((uint32_t)(x >> 32)) : lane_xor32((uint32_t)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -545,8 +570,8 @@ __device__ __forceinline__ void merge_lane_groups(KeyList& L) {
     for (int i = 0; i < MAX_TOPK; ++i) {
         const unsigned long long h = L.k[0];
         unsigned long long m = h;
-        unsigned long long o = shfl_xor_u64(m, 16); m = o > m ? o : m;
-        o = shfl_xor_u64(m, 32); m = o > m ? o : m;
+        unsigned long long o = lane_xor_u64<16>(m); m = o > m ? o : m;
+        o = lane_xor_u64<32>(m); m = o > m ? o : m;
         R.k[i] = m;
         if (h == m && m != 0ull) L.pop();
     }

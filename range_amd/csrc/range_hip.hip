@@ -95,6 +95,7 @@ struct range_ctx {
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
     bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 32 queries take the two-pass kernels too (A/B)
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
+    DevBuf<uint32_t> ws_read_sink;           // range_stream_read_timed: one word per workgroup
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
@@ -1228,6 +1229,63 @@ int range_topk_stream_timed(range_ctx* c, const float* ehat32, int64_t B, int32_
                             int64_t* topk_idx, int32_t repeats, float* avg_us, range_stream_t stream) {
     if (repeats < 2 || !avg_us) return fail(RANGE_ERR_INVALID, "repeats must be >= 2 and avg_us non-null");
     return topk_stream_impl(c, ehat32, B, k, topk_val, topk_idx, repeats, avg_us, stream);
+}
+
+// A plain one-launch streaming read of the same bytes the top-k scan streams (`passes` times over
+// the bf16 or the float32 copy of the keys): the ceiling a launch of that size can reach on this
+// chip, measured the same way as range_topk_stream_timed.  16-byte non-temporal loads, 8 in flight
+// per thread, 1 024 workgroups; the xor of everything read goes to one word per workgroup so that
+// the loads stay.
+__global__ __launch_bounds__(256) void stream_read_kernel(const ts_u32x4* __restrict__ p, int64_t n16, int passes,
+                                                          uint32_t* __restrict__ sink) {
+    // a workgroup reads 32 KB contiguous per step (8 loads of 16 bytes per thread, 4 KB apart)
+    const int64_t step = (int64_t)gridDim.x * 2048;
+    ts_u32x4 acc = {0u, 0u, 0u, 0u};
+    for (int ps = 0; ps < passes; ++ps) {
+        for (int64_t base = (int64_t)blockIdx.x * 2048; base < n16; base += step) {
+            ts_u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = base + u * 256 + threadIdx.x;
+                v[u] = __builtin_nontemporal_load(p + (i < n16 ? i : n16 - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+    }
+    uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) r ^= __shfl_xor(r, off);
+    if ((threadIdx.x & 63) == 0) atomicXor(sink + blockIdx.x, r);
+}
+
+int range_stream_read_timed(range_ctx* c, int32_t f32_keys, int32_t passes, int32_t repeats, float* avg_us,
+                            range_stream_t stream) {
+    if (!c || !avg_us) return fail(RANGE_ERR_INVALID, "null argument");
+    if (!c->has_bank) return fail(RANGE_ERR_STATE, "bank not set (range_set_bank)");
+    if (passes < 1 || repeats < 2) return fail(RANGE_ERR_INVALID, "passes must be >= 1 and repeats >= 2");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_tiles = c->n_pad / BLK;
+    const ts_u32x4* src = f32_keys ? reinterpret_cast<const ts_u32x4*>(c->d_keys.p) : reinterpret_cast<const ts_u32x4*>(c->d_keys_bf16.p);
+    const int64_t n16 = f32_keys ? c->n_pad * (KEY_DIM * 4 / 16) : n_tiles * (TSB_TILE_BYTES / 16);
+    const int grid = 4 * c->n_cu;
+    HIP_TRY(c->ws_read_sink.ensure((size_t)grid));
+    hipEvent_t ev0 = c->get_event(), ev1 = c->get_event();
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, s, src, n16, passes, c->ws_read_sink.p);   // (warm-up)
+    HIP_TRY(hipEventRecord(ev0, s));
+    for (int rep = 0; rep < repeats; ++rep)
+        hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, s, src, n16, passes, c->ws_read_sink.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, s));
+    HIP_TRY(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    *avg_us = ms * 1e3f / (float)repeats;
+    c->ev_pool.push_back(ev0);
+    c->ev_pool.push_back(ev1);
+    return RANGE_OK;
 }
 
 int range_topk_stream_exact_count(range_ctx* c, int64_t* count) {

@@ -138,33 +138,35 @@ struct ShortList {
 // sequence, which log2(L) stages of compare-exchanges sort.  `drop` receives the largest key this
 // LANE saw leave; the two lanes of a pair see the same pairs, but the first round of lanes (2,3)
 // is invisible to lanes (0,1): the caller reduces `drop` over the 4 lanes (merge4_drop_max).
-template <int L>
-__device__ __forceinline__ void merge4_short(unsigned long long (&k)[L], unsigned long long& drop) {
-    static_assert(L == 4 || L == 8 || L == 16, "power-of-two list");
+template <int L, int OFF>
+__device__ __forceinline__ void merge4_short_round(unsigned long long (&k)[L], unsigned long long& drop) {
+    unsigned long long p[L];
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        unsigned long long p[L];
+    for (int i = 0; i < L; ++i) p[i] = lane_xor_u64<OFF>(k[L - 1 - i]);
 #pragma unroll
-        for (int i = 0; i < L; ++i) p[i] = shfl_xor_u64(k[L - 1 - i], off);
+    for (int i = 0; i < L; ++i) {
+        const bool up = k[i] > p[i];
+        const unsigned long long lo = up ? p[i] : k[i];
+        k[i] = up ? k[i] : p[i];
+        drop = lo > drop ? lo : drop;
+    }
+#pragma unroll
+    for (int d = L / 2; d >= 1; d >>= 1) {
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const bool up = k[i] > p[i];
-            const unsigned long long lo = up ? p[i] : k[i];
-            k[i] = up ? k[i] : p[i];
-            drop = lo > drop ? lo : drop;
-        }
-#pragma unroll
-        for (int d = L / 2; d >= 1; d >>= 1) {
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                if ((i & d) == 0) {
-                    const unsigned long long a = k[i], b = k[i + d];
-                    k[i] = a > b ? a : b;
-                    k[i + d] = a > b ? b : a;
-                }
+            if ((i & d) == 0) {
+                const unsigned long long a = k[i], b = k[i + d];
+                k[i] = a > b ? a : b;
+                k[i + d] = a > b ? b : a;
             }
         }
     }
+}
+template <int L>
+__device__ __forceinline__ void merge4_short(unsigned long long (&k)[L], unsigned long long& drop) {
+    static_assert(L == 4 || L == 8 || L == 16, "power-of-two list");
+    merge4_short_round<L, 16>(k, drop);
+    merge4_short_round<L, 32>(k, drop);
 }
 // compare-exchange: afterwards a >= b
 __device__ __forceinline__ void topk_cmpx(unsigned long long& a, unsigned long long& b) {
@@ -178,7 +180,7 @@ __device__ __forceinline__ void topk_cmpx(unsigned long long& a, unsigned long l
 // sorted lists of 8, as in merge4_short.
 __device__ __forceinline__ void merge4_lists4_top8(unsigned long long (&k)[8], unsigned long long& drop) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k[4 + i] = shfl_xor_u64(k[3 - i], 16);          // [own descending | partner ascending]
+    for (int i = 0; i < 4; ++i) k[4 + i] = lane_xor_u64<16>(k[3 - i]);          // [own descending | partner ascending]
 #pragma unroll
     for (int d = 4; d >= 1; d >>= 1) {
 #pragma unroll
@@ -188,7 +190,7 @@ __device__ __forceinline__ void merge4_lists4_top8(unsigned long long (&k)[8], u
     }
     unsigned long long p[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = shfl_xor_u64(k[7 - i], 32);
+    for (int i = 0; i < 8; ++i) p[i] = lane_xor_u64<32>(k[7 - i]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bool up = k[i] > p[i];
@@ -207,8 +209,8 @@ __device__ __forceinline__ void merge4_lists4_top8(unsigned long long (&k)[8], u
 // dmax of the merged list: the lanes' own dmax, and everything the merge dropped in ANY of the 4 lanes
 __device__ __forceinline__ float merge4_drop_max(float dm, unsigned long long drop) {
     if (drop != 0ull) dm = fmaxf(dm, topk_key_val(drop));
-    dm = fmaxf(dm, __shfl_xor(dm, 16));
-    dm = fmaxf(dm, __shfl_xor(dm, 32));
+    dm = fmaxf(dm, lane_xor16(dm));
+    dm = fmaxf(dm, lane_xor32(dm));
     return dm;
 }
 

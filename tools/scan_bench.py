@@ -72,7 +72,9 @@ def main():
                 passes = (groups + per_pass - 1) // per_pass
                 row = 512 if mode == "bf16" else 1024
                 streamed = passes * n * row
+                copy_us = sum(eng.stream_read_timed(mode == "f32", passes, 20) for _ in range(3)) / 3
                 print(json.dumps({"N": n, "queries": nq, "keys": mode, "passes": passes, "us_per_call": round(us, 2),
+                                  "plain_read_us": round(copy_us, 2), "frac_of_copy": round(copy_us / us, 4),
                                   "streamed_MB": streamed / 1e6, "streamed_TBps": round(streamed / us / 1e6, 3),
                                   "frac_streamed": round(streamed / us / 1e6 / 8.0, 4),
                                   "cold": a.cold, "queries_with_all_16_indices_equal_f64": same,
