@@ -135,8 +135,16 @@ def cpu_model_name():
 
 def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     """The oracle (CPU restatement of the reference, torch CPU ops in the reference's order and
-    dtypes) timed on this box's host cores on a bounded sample of the same workload: all threads
-    with the SH / Siren / retrieval split of SURVEY.md 8(d), and one thread on a smaller sample."""
+    dtypes) timed on this box's host cores on a bounded sample of the same workload.
+
+    ``value`` is the REFERENCE-SHAPED port: the spherical harmonics evaluated the way the reference
+    evaluates them - L*L = 1600 functions per batch, each a fully expanded float64 polynomial whose
+    powers are formed inside it (spherical_harmonics.py:35-42 over the generated file; 70 % of the
+    reference's CPU time) - through ``oracle.sh_features_faithful``, which is pinned
+    BITWISE to the reference's features (tests/test_oracle_golden.py).  ``port_recurrence`` is the
+    same path with the stable three-term recurrence instead (what a sensible CPU port would run):
+    reported beside it, never instead of it.  All threads with the SH / Siren / retrieval split, and
+    one thread on a smaller sample."""
     import numpy as np
     import torch
     from oracle import range_oracle as O     # checker / baseline only
@@ -144,13 +152,14 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     locs, vals, keys = bank_arrays
     obank = O.prep_bank(locs, vals, keys)
     q = synth.make_queries(n_sample, seed=7, lat_max=90.0)
+    table = O.load_ylm_table()
 
-    def run(qs, chunk):
+    def run(qs, chunk, faithful):
         t_sh = t_si = t_re = 0.0
         for i in range(0, qs.shape[0], chunk):
             ll = qs[i:i + chunk]
             t0 = time.perf_counter()
-            y = O.sh_features(ll, L, "analytic")
+            y = O.sh_features_faithful(ll, table, L) if faithful else O.sh_features(ll, L, "analytic")
             t1 = time.perf_counter()
             e = torch.from_numpy(O.siren_forward(y, weights))
             e = (e / e.norm(p=2, dim=-1, keepdim=True)).numpy()
@@ -163,25 +172,37 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
         return t_sh, t_si, t_re
 
     n_all = torch.get_num_threads()
-    run(q[:64], 64)                                            # warm-up
-    sh, si, re_ = run(q, 512)
-    dt = sh + si + re_
-    n1 = max(32, min(192, n_sample // 16))
-    torch.set_num_threads(1)
-    try:
-        sh1, si1, re1 = run(q[:n1], n1)
-    finally:
-        torch.set_num_threads(n_all)
-    dt1 = sh1 + si1 + re1
-    return {"value": n_sample / dt, "unit": "geo-embeddings/sec", "cores": n_all,
-            "kind": "port",
-            "sample": f"{n_sample} of the 10000-query batch, same bank, chunks of 512, "
-                      f"{dt:.1f} s; host: {cpu_model_name()}, {os.cpu_count()} logical CPUs",
-            "split_s": {"sh_features": sh, "siren": si, "retrieval": re_},
-            "split_q_per_s": {"sh_features": n_sample / sh, "siren": n_sample / si,
-                              "retrieval": n_sample / re_},
-            "one_thread": {"value": n1 / dt1, "cores": 1, "sample": f"{n1} queries, {dt1:.1f} s",
-                           "split_s": {"sh_features": sh1, "siren": si1, "retrieval": re1}}}
+    host = f"host: {cpu_model_name()}, {os.cpu_count()} logical CPUs"
+
+    def leg(faithful):
+        run(q[:64], 64, faithful)                                  # warm-up
+        sh, si, re_ = run(q, 512, faithful)
+        dt = sh + si + re_
+        n1 = max(32, min(192, n_sample // 16))
+        torch.set_num_threads(1)
+        try:
+            sh1, si1, re1 = run(q[:n1], n1, faithful)
+        finally:
+            torch.set_num_threads(n_all)
+        dt1 = sh1 + si1 + re1
+        return {"value": n_sample / dt, "unit": "geo-embeddings/sec", "cores": n_all,
+                "sample": f"{n_sample} of the 10000-query batch, same bank, chunks of 512, {dt:.1f} s; {host}",
+                "split_s": {"sh_features": sh, "siren": si, "retrieval": re_},
+                "split_q_per_s": {"sh_features": n_sample / sh, "siren": n_sample / si,
+                                  "retrieval": n_sample / re_},
+                "one_thread": {"value": n1 / dt1, "cores": 1, "sample": f"{n1} queries, {dt1:.1f} s",
+                               "split_s": {"sh_features": sh1, "siren": si1, "retrieval": re1}}}
+
+    res = leg(True)
+    res["kind"] = "port"
+    res["shape"] = ("reference-shaped: spherical harmonics as the reference evaluates them (1600 expanded float64 "
+                    "polynomials per batch, one torch expression per (l,m); bitwise the reference's features), "
+                    "SirenNet and retrieval in the reference's op order and dtypes")
+    fast = leg(False)
+    fast["kind"] = "port"
+    fast["shape"] = "the same path with the spherical harmonics by the stable recurrence (not what the reference runs)"
+    res["port_recurrence"] = fast
+    return res
 
 
 def pmc_traffic(kernel, B, N, qt, ns):
@@ -373,7 +394,7 @@ def main():
         # e-hat against the oracle fed with the same SH polynomials (CPU evaluation of the table;
         # queries run pole to pole, where the reference's polynomials are ill-conditioned and the
         # last bit of pow() shows: inside |lat| <= 45 the two agree to 1e-7), retrieval given e-hat
-        e = O.encode(qs, weights, L, features=table.evaluate(qs))
+        e = O.encode(qs, weights, L, features=O.sh_features_faithful(qs, O.load_ylm_table(), L))
         band = np.abs(qs[:, 1]) <= 45.0
         got_e = got[:, 1024:]
         ref32 = O.retrieve(got_e, qs, obank, "RANGE+", beta_chk)

@@ -104,6 +104,87 @@ def sh_features(lonlat: np.ndarray, L: int, mode: str = "analytic") -> np.ndarra
     return Y
 
 
+@dataclass
+class YlmTable:
+    """The numbers of the reference's generated ``spherical_harmonics_ylm.py`` (one function per
+    (l, m); generator: spherical_harmonics_generate_ylms.py:19-40), parsed into arrays indexed
+    ``l*L + m`` for 0 <= m <= l < L:
+
+        Y_l^m = front * (a0 + a2 x^2)^(p2/2) * (sum_j coef[off+j] * x^pow[off+j]) * x^kx * cos|sin(m phi),
+        x = cos(theta)
+
+    Loaded from the committed fixture ``tests/golden/ylm_table_L40.npz`` (data the reference's
+    generator printed; tests/golden/make_golden_shtable.py)."""
+    L: int
+    front: np.ndarray
+    a0: np.ndarray
+    a2: np.ndarray
+    p2: np.ndarray
+    kx: np.ndarray
+    off: np.ndarray
+    cnt: np.ndarray
+    coef: np.ndarray
+    pow: np.ndarray
+
+
+#: the committed fixture with the numbers of the reference's generated functions up to L = 40
+YLM_FIXTURE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+    __import__("os").path.abspath(__file__))), "tests", "golden", "ylm_table_L40.npz")
+
+
+def load_ylm_table(path: str = YLM_FIXTURE) -> YlmTable:
+    z = np.load(path, allow_pickle=False)
+    return YlmTable(int(z["L"]), *[np.asarray(z[k]) for k in
+                                   ("front", "a0", "a2", "p2", "kx", "off", "cnt", "coef", "pow")])
+
+
+def sh_features_faithful(lonlat: np.ndarray, table: YlmTable, L: Optional[int] = None) -> np.ndarray:
+    """The 'analytic' features THE WAY THE REFERENCE EVALUATES THEM
+    (spherical_harmonics.py:27-42 over the generated spherical_harmonics_ylm.py): one function per
+    (l, m), m = -l..l - L*L calls, each a fully expanded float64 polynomial in cos(theta) whose
+    powers are formed by ``torch.pow`` inside that function, every product and every sum an op of
+    its own on the (B,) batch - then ``torch.stack``.  Nothing is shared between functions: the
+    polynomial of (l, |m|) is evaluated again for -m, cos(theta) again in every function.  This is
+    both the reference's rounding (ill-conditioned towards the poles: SURVEY.md section 0 fact 4)
+    and the reference's COST (70 % of its CPU time) - ``bench.py``'s ``reference-shaped`` CPU baseline."""
+    L = table.L if L is None else int(L)
+    if L > table.L:
+        raise ValueError(f"table holds L={table.L}, asked for {L}")
+    TL = table.L
+    lonlat_t = torch.from_numpy(np.ascontiguousarray(lonlat, dtype=np.float64))
+    phi = torch.deg2rad(lonlat_t[:, 0] + 180)                   # spherical_harmonics.py:31
+    theta = torch.deg2rad(lonlat_t[:, 1] + 90)                  # :32
+    Y: List[torch.Tensor] = []
+    for l in range(L):
+        for m in range(-l, l + 1):                              # :35-36
+            i = l * TL + abs(m)
+            front, p2, kx, off, cnt = float(table.front[i]), int(table.p2[i]), int(table.kx[i]), int(table.off[i]), int(table.cnt[i])
+            if p2 == 0 and cnt == 0 and kx == 0 and m == 0:
+                Y.append(front * torch.ones_like(phi))          # :38-39 (Y00 is a Python float)
+                continue
+            ct = torch.cos(theta)
+            v: object = front
+            if p2:
+                v = v * (float(table.a0[i]) + float(table.a2[i]) * ct ** 2) ** (p2 / 2.0)
+            if cnt:
+                ssum = None
+                for j in range(off, off + cnt):
+                    pj = int(table.pow[j])
+                    t = float(table.coef[j]) * (ct ** pj) if pj else torch.full_like(ct, float(table.coef[j]))
+                    ssum = t if ssum is None else ssum + t
+                v = v * ssum
+            # (sympy prints the factors of a product in its canonical order: cos(m*phi) / sin(m*phi)
+            # in front of a bare cos(theta)**kx factor - which only functions without a polynomial have)
+            if m > 0:
+                v = v * torch.cos(m * phi)
+            elif m < 0:
+                v = v * torch.sin(-m * phi)
+            if kx:
+                v = v * (ct ** kx if kx > 1 else ct)
+            Y.append(v if torch.is_tensor(v) else v * torch.ones_like(phi))
+    return torch.stack(Y, dim=-1).numpy()                       # :42
+
+
 # --------------------------------------------------------------------------------------------
 # R2  SirenNet  (satclip/location_encoder.py:98-112, 114-119, 146-151)
 # --------------------------------------------------------------------------------------------

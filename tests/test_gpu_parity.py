@@ -135,9 +135,9 @@ def test_encoder_reference_mode_over_all_latitudes():
         assert d[m].max() < tol, (lo, hi, d[m].max())
     assert d.max() < 1.5e-3          # ... and the north-star 1e-4 holds on |lat| <= 60 now
     assert d[al <= 60].max() < 1e-4
-    # the same numbers from the CPU evaluation of the table (numpy pow instead of correctly
-    # rounded powers: agreement to the same few bits of pow)
-    ref = O.encode(q, w, L, features=table.evaluate(q))
+    # the same numbers from the oracle's reference-shaped CPU evaluation (bitwise the reference's
+    # features; torch's pow instead of correctly rounded powers: agreement to the same few bits of pow)
+    ref = O.encode(q, w, L, features=O.sh_features_faithful(q, O.load_ylm_table(), L))
     assert np.abs(e64 - ref)[al <= 45].max() < 1e-7 and np.abs(e64 - ref).max() < 1.5e-3
     # a table parsed from generated text gives the same engine state as the generated table
     eng.set_encoder(L, enc.hidden, enc.num_hidden_layers, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)

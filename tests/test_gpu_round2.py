@@ -93,7 +93,7 @@ def test_reference_sh_tables_of_other_degrees(L):
     eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs, sh_table=table)
     q = synth.make_queries(700, seed=L, lat_max=90.0)
     e = eng.encode(torch.from_numpy(q).cuda())[0].cpu().numpy()
-    ref = O.encode(q, w, L, features=table.evaluate(q))
+    ref = O.encode(q, w, L, features=O.sh_features_faithful(q, O.load_ylm_table(), L))   # (bitwise the reference's features)
     band = np.abs(q[:, 1]) <= 45
     assert np.abs(e - ref)[band].max() < 1e-7 and np.abs(e - ref).max() < (1e-9 if L <= 16 else 2e-3)
     if L <= 16:
@@ -301,7 +301,8 @@ def test_encoder_wide_hidden_layers(L, H, layers, mode, Bs):
         x = torch.from_numpy(q).cuda()
         for eng, tab in engines:
             e64, e32, xq = eng.encode(x)
-            ref = O.encode(q, w, L, mode) if tab is None else O.encode(q, w, L, features=tab.evaluate(q))
+            ref = (O.encode(q, w, L, mode) if tab is None else
+                   O.encode(q, w, L, features=O.sh_features_faithful(q, O.load_ylm_table(), L)))
             np.testing.assert_allclose(e64.cpu().numpy(), ref, rtol=0, atol=4e-12 if tab is None else 2e-7)
             np.testing.assert_array_equal(e32.cpu().numpy(), e64.cpu().numpy().astype(np.float32))
             raw = eng.encode_raw(x).cpu().numpy()

@@ -169,3 +169,46 @@ def test_encoder_over_all_latitudes_vs_reference():
     assert d[al <= 45].max() < 1e-5 and d[al > 60].max() > 1e-4
     # the reference does not reproduce itself either: its spread grows the same way
     assert z["self_spread"][al > 60].max() > 1e-6 > z["self_spread"][al <= 30].max()
+
+
+# ---- the reference-SHAPED evaluation of the 'analytic' basis (oracle.sh_features_faithful): one float64
+#      torch expression per (l, m) over the numbers the reference's generator printed
+YLM = os.path.join(GOLDEN, "ylm_table_L40.npz")
+
+
+def test_faithful_sh_features_equal_the_reference_bitwise():
+    """Pole to pole, every one of the 1600 functions of L = 40: the oracle's reference-shaped
+    evaluation IS the reference's (spherical_harmonics.py:27-42 over the generated file), bit for
+    bit - also where those polynomials have lost every digit to cancellation."""
+    z = np.load(YLM)
+    tab = O.load_ylm_table(YLM)
+    Y = O.sh_features_faithful(z["lonlat"], tab)
+    assert np.abs(z["lonlat"][:, 1]).max() > 89.0
+    assert Y.dtype == np.float64 and np.array_equal(Y, z["sh_features"])
+    # lower L: the functions of degree l < L do not depend on L
+    for tag in ("enc_analytic_L10_H64_n2", "enc_analytic_L16_H128_n3", "enc_analytic_L40_H512_n2"):
+        g = np.load(os.path.join(GOLDEN, tag + ".npz"))
+        # (the whole batch, as the reference evaluated it: torch's vectorised pow rounds the last
+        # elements of a batch - its scalar tail - differently from the ones in full SIMD groups, the
+        # reference's own "batch vs single" spread of SURVEY.md section 8(c))
+        Yg = O.sh_features_faithful(g["lonlat"], tab, int(g["L"]))[g["sh_rows"]]
+        assert np.array_equal(Yg, g["sh_features"]), tag
+
+
+@pytest.mark.parametrize("tag", ["enc_analytic_L10_H64_n2", "enc_analytic_L16_H128_n3", "enc_analytic_L40_H256_n2",
+                                 "enc_analytic_L40_H512_n2", "latitude_L40_H512_n2"])
+def test_faithful_encoder_matches_the_reference_at_every_latitude(tag):
+    """With the reference's own features the restated SirenNet + normalisation reproduce the
+    reference's embedding to float64 rounding at EVERY latitude (the exact basis of ``sh_features``
+    agrees only inside |lat| <= 45: LAT_BANDS above)."""
+    g = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    L, H = int(g["L"]), int(g["hidden"])
+    w = synth.make_encoder_weights(L, H, 256, int(g["num_hidden_layers"]), int(g["seed"]))
+    q = g["lonlat"]
+    feats = O.sh_features_faithful(q, O.load_ylm_table(YLM), L)
+    if tag.startswith("enc_"):        # (these fixtures hold the SirenNet output before the normalisation)
+        e = O.siren_forward(feats, w)
+        assert float(np.abs(e - g["embedding"]).max()) < 1e-12 * max(1.0, float(np.abs(g["embedding"]).max()))
+    else:
+        e = O.encode(q, w, L, features=feats)
+        assert np.abs(q[:, 1]).max() > 89.0 and float(np.abs(e - g["embedding"]).max()) < 1e-14

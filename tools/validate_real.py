@@ -108,7 +108,8 @@ def main():
         # e-hat against the oracle fed with the same SH polynomials (CPU evaluation of the table)
         from range_amd.range import sh_table_for
         tab = sh_table_for(enc, None, kw.get("sh_source"))
-        e_ref = O.encode(q, w, L, features=tab.evaluate(q)) if tab is not None else O.encode(q, w, L, enc.harmonics_calculation)
+        e_ref = (O.encode(q, w, L, features=O.sh_features_faithful(q, O.load_ylm_table(), L)) if tab is not None and L <= 40
+                 else O.encode(q, w, L, features=tab.evaluate(q)) if tab is not None else O.encode(q, w, L, enc.harmonics_calculation))
         band = np.abs(q[:, 1]) <= 45
         d_e, d_e_all = float(np.abs(e - e_ref)[band].max()), float(np.abs(e - e_ref).max())
         d64 = float(np.abs(out[:, :1024] - O.retrieve64(e, q, obank, name, 0.5)).max())
