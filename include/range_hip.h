@@ -54,7 +54,8 @@ typedef void* range_stream_t; /* hipStream_t */
  * hyper_parameters (satclip/main_old.py:15-37; satclip/model_old.py:326-330). */
 typedef struct range_encoder_desc {
     int32_t legendre_polys;    /* L; SH feature count is L*L (spherical_harmonics.py:19-20) */
-    int32_t hidden;            /* capacity H; a multiple of 64 up to 512, or 768, or 1024 */
+    int32_t hidden;            /* capacity H, 1..1024 (kernels exist for multiples of 64 up to 512, 768, 1024;
+                                  other widths run zero-padded to the next of those: same result, bit for bit) */
     int32_t num_hidden_layers; /* SirenNet num_layers (>= 1) */
     int32_t embed_dim;         /* must be RANGE_KEY_DIM */
     int32_t sh_mode;           /* RANGE_SH_ANALYTIC | RANGE_SH_CLOSED_FORM (spherical_harmonics.py:22-25) */

@@ -545,10 +545,15 @@ int64_t range_bank_rows(const range_ctx* ctx) { return ctx ? ctx->n_rows : 0; }
 int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* const* weights,
                       const double* const* biases) {
     if (!c || !d || !weights || !biases) return fail(RANGE_ERR_INVALID, "null argument");
-    const int L = d->legendre_polys, H = d->hidden, NL = d->num_hidden_layers, E = d->embed_dim;
+    const int L = d->legendre_polys, Hc = d->hidden, NL = d->num_hidden_layers, E = d->embed_dim;
     if (L < 1 || L > 64) return fail(RANGE_ERR_INVALID, "legendre_polys %d unsupported (1..64)", L);
-    if (!((H >= 64 && H <= 512 && H % 64 == 0) || H == 768 || H == 1024))
-        return fail(RANGE_ERR_INVALID, "hidden %d unsupported (multiples of 64 up to 512, 768, 1024)", H);
+    if (Hc < 1 || Hc > 1024) return fail(RANGE_ERR_INVALID, "hidden %d unsupported (1..1024)", Hc);
+    // The kernels exist for hidden widths that are multiples of 64 up to 512, and 768 and 1024.  Any
+    // other width of the checkpoint (`capacity` of the real one is unknown) runs as the next of those
+    // with ZERO-PADDED weights: a padded hidden unit is sin(w0 (0 . x + 0)) = 0 and feeds zero weights,
+    // every product it adds is an exact +0.0 - the result is the unpadded network's, bit for bit in
+    // the same summation order, at the padded width's cost.
+    const int H = Hc <= 512 ? (Hc + 63) / 64 * 64 : (Hc <= 768 ? 768 : 1024);
     if (NL < 1 || NL + 1 > ENC_MAX_LAYERS) return fail(RANGE_ERR_INVALID, "num_hidden_layers %d unsupported", NL);
     if (E != ENC_EMBED) return fail(RANGE_ERR_INVALID, "embed_dim %d unsupported (must be 256)", E);
     if (d->sh_mode != RANGE_SH_ANALYTIC && d->sh_mode != RANGE_SH_CLOSED_FORM)
@@ -573,12 +578,25 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
         return pack_weights(W, n_out, k_in, kperm, Kpad);
     };
     for (int i = 0; i <= NL; ++i) if (!weights[i] || !biases[i]) return fail(RANGE_ERR_INVALID, "weights[%d]/biases[%d] null", i, i);
-    HIP_TRY(c->d_wp[0].upload(pack(weights[0], H, L * L, &perm, Kp)));
-    for (int i = 1; i < NL; ++i) HIP_TRY(c->d_wp[i].upload(pack(weights[i], H, H, nullptr, H)));
-    HIP_TRY(c->d_wp[NL].upload(pack(weights[NL], E, H, nullptr, H)));
+    // (n_out x k_in) of the checkpoint -> (n_pad x k_pad), the new rows and columns zero
+    auto padded = [](const double* W, int n_out, int k_in, int n_pad, int k_pad) {
+        std::vector<double> P((size_t)n_pad * k_pad, 0.0);
+        for (int r = 0; r < n_out; ++r) std::copy(W + (size_t)r * k_in, W + (size_t)(r + 1) * k_in, P.begin() + (size_t)r * k_pad);
+        return P;
+    };
+    if (H == Hc) {
+        HIP_TRY(c->d_wp[0].upload(pack(weights[0], H, L * L, &perm, Kp)));
+        for (int i = 1; i < NL; ++i) HIP_TRY(c->d_wp[i].upload(pack(weights[i], H, H, nullptr, H)));
+        HIP_TRY(c->d_wp[NL].upload(pack(weights[NL], E, H, nullptr, H)));
+    } else {
+        HIP_TRY(c->d_wp[0].upload(pack(padded(weights[0], Hc, L * L, H, L * L).data(), H, L * L, &perm, Kp)));
+        for (int i = 1; i < NL; ++i) HIP_TRY(c->d_wp[i].upload(pack(padded(weights[i], Hc, Hc, H, H).data(), H, H, nullptr, H)));
+        HIP_TRY(c->d_wp[NL].upload(pack(padded(weights[NL], E, Hc, E, H).data(), E, H, nullptr, H)));
+    }
     for (int i = 0; i <= NL; ++i) {
-        const int n = i < NL ? H : E;
-        HIP_TRY(c->d_bias[i].upload(std::vector<double>(biases[i], biases[i] + n)));
+        std::vector<double> b((size_t)(i < NL ? H : E), 0.0);
+        std::copy(biases[i], biases[i] + (i < NL ? Hc : E), b.begin());
+        HIP_TRY(c->d_bias[i].upload(b));
     }
     HIP_TRY(c->d_slot_base.upload(slot_base));
     HIP_TRY(c->d_coefA.upload(coefA));

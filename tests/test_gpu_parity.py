@@ -129,16 +129,16 @@ def test_encoder_reference_mode_over_all_latitudes():
     np.testing.assert_array_equal(e32.cpu().numpy(), e64.astype(np.float32))
     d = np.abs(e64 - z["embedding"]).max(axis=1)
     al = np.abs(q[:, 1])
-    # measured: 4e-11 / 3e-8 / 2e-6 / 8e-5 / 2e-4 (the exact basis: 8e-10 / 8e-7 / 2e-4 / 3e-3 / 6e-3)
-    for (lo, hi, _), tol in zip(LAT_BANDS, (1e-9, 5e-7, 3e-5, 6e-4, 1.5e-3)):
+    # bounds = 2x measured (tools/latitude_bands.py, round 4: 7.3e-11 / 5.0e-8 / 5.3e-6 / 1.0e-4 / 2.6e-4;
+    # the exact basis: 7e-10 / 6e-7 / 1.4e-4 / 3e-3 / 6e-3) - the figures INTEGRATION.md quotes
+    for (lo, hi, _), tol in zip(LAT_BANDS, (2e-10, 1e-7, 1.1e-5, 2e-4, 5.5e-4)):
         m = (al >= lo) & (al < hi)
         assert d[m].max() < tol, (lo, hi, d[m].max())
-    assert d.max() < 1.5e-3          # ... and the north-star 1e-4 holds on |lat| <= 60 now
-    assert d[al <= 60].max() < 1e-4
+    assert d[al <= 60].max() < 1e-4  # ... and the north-star 1e-4 holds on |lat| <= 60
     # the same numbers from the oracle's reference-shaped CPU evaluation (bitwise the reference's
     # features; torch's pow instead of correctly rounded powers: agreement to the same few bits of pow)
     ref = O.encode(q, w, L, features=O.sh_features_faithful(q, O.load_ylm_table(), L))
-    assert np.abs(e64 - ref)[al <= 45].max() < 1e-7 and np.abs(e64 - ref).max() < 1.5e-3
+    assert np.abs(e64 - ref)[al <= 45].max() < 1e-7 and np.abs(e64 - ref).max() < 5.5e-4
     # a table parsed from generated text gives the same engine state as the generated table
     eng.set_encoder(L, enc.hidden, enc.num_hidden_layers, 256, _native.SH_ANALYTIC, enc.weights, enc.biases)
     ex = eng.encode(_dev(q))[0].cpu().numpy()          # no table: back to the exact recurrence
@@ -359,11 +359,11 @@ def test_errors_and_edge_cases():
     w, enc = _params(10, 64, 2, 5)
     with pytest.raises(ValueError):
         eng.set_encoder(10, 128, 2, 256, 0, enc.weights, enc.biases)   # shapes do not match H
-    bad = synth.make_encoder_weights(10, 96, 256, 2, 5)
+    bad = synth.make_encoder_weights(10, 1100, 256, 2, 5)
     ws = [bad["layers.0.weight"], bad["layers.1.weight"], bad["last_layer.weight"]]
     bs = [bad["layers.0.bias"], bad["layers.1.bias"], bad["last_layer.bias"]]
-    with pytest.raises(_native.RangeNativeError):
-        eng.set_encoder(10, 96, 2, 256, 0, ws, bs)                     # H not a multiple of 64
+    with pytest.raises(_native.RangeNativeError, match="unsupported"):
+        eng.set_encoder(10, 1100, 2, 256, 0, ws, bs)                   # H beyond 1024 (any width up to it loads)
 
 
 def test_sharded_path_over_rccl_world1(tmp_path):

@@ -309,8 +309,25 @@ def test_encoder_wide_hidden_layers(L, H, layers, mode, Bs):
             np.testing.assert_allclose(raw / np.linalg.norm(raw, axis=1, keepdims=True), e64.cpu().numpy(), rtol=0, atol=1e-13)
     with pytest.raises(_native.RangeNativeError, match="unsupported"):
         bad = _native.HipEngine("cuda:0")
-        wb, wsb, bsb = _weights(10, 640, 2, 1)
-        bad.set_encoder(10, 640, 2, 256, _native.SH_ANALYTIC, wsb, bsb)
+        wb, wsb, bsb = _weights(10, 1088, 2, 1)
+        bad.set_encoder(10, 1088, 2, 256, _native.SH_ANALYTIC, wsb, bsb)
+
+
+@pytest.mark.parametrize("H", [100, 576, 640, 704, 832, 896, 960, 1000])
+def test_hidden_widths_between_the_kernels_run_zero_padded(H):
+    """`capacity` of the real checkpoint is unknown: ANY hidden width up to 1024 loads.  Widths no
+    kernel exists for run as the next one that has (multiples of 64 up to 512, 768, 1024) with
+    zero-padded weights - a padded unit is sin(0) = 0 feeding zero weights, every product it adds an
+    exact +0.0 - and equal the float64 oracle of the UNPADDED network like every other width."""
+    L = 12
+    w, ws, bs = _weights(L, H, 2, 30 + H)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_encoder(L, H, 2, 256, _native.SH_CLOSED_FORM, ws, bs)
+    for B in (7, 300, 5000):
+        q = synth.make_queries(B, seed=B + H, lat_max=89.0)
+        e64, e32, xq = eng.encode(torch.from_numpy(q).cuda())
+        np.testing.assert_allclose(e64.cpu().numpy(), O.encode(q, w, L, "closed-form"), rtol=0, atol=4e-12)
+        np.testing.assert_array_equal(e32.cpu().numpy(), e64.cpu().numpy().astype(np.float32))
 
 
 @pytest.mark.parametrize("N", [9, 1000, 20011])

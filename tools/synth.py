@@ -210,3 +210,47 @@ PROBE_CASES = {
     "cls_ocean": ("ocean", dict(kind="classification", n_train=2000, n_val=500, dim=1280,
                                 seed=108, n_classes=2)),
 }
+
+
+def write_ylm_source(path: str, L: int) -> str:
+    """A ``spherical_harmonics_ylm.py`` in the syntax of the reference's generator
+    (spherical_harmonics_generate_ylms.py:37-41: one ``def Yl{l}_m{m}(theta, phi): return <expr>``
+    per (l, m), sympy's printing of products and sums), rendered from the regenerated coefficient
+    table - a stand-in for the user's generated file in tests of ``load_model(sh_source=)`` and
+    ``tools/validate_real.py`` (the real file is absent from the snapshot: SURVEY.md fact 3)."""
+    from range_amd import sh_table
+    t = sh_table.generate_table(L)
+
+    def poly(terms):
+        out = ""
+        for n, (c, k) in enumerate(terms):
+            mag = repr(abs(float(c)))
+            body = mag if k == 0 else (f"{mag}*cos(theta)" if k == 1 else f"{mag}*cos(theta)**{k}")
+            out += (("-" if c < 0 else "") + body) if n == 0 else ((" - " if c < 0 else " + ") + body)
+        return out
+
+    lines = ["import torch", "from torch import cos, sin", ""]
+    for l in range(L):
+        for m in range(-l, l + 1):
+            i = l * L + abs(m)
+            terms = [(float(t.coef[j]), int(t.pow[j])) for j in range(int(t.off[i]), int(t.off[i]) + int(t.cnt[i]))]
+            front, kx, p2 = float(t.front[i]), int(t.kx[i]), int(t.p2[i])
+            if m == 0:
+                expr = poly(terms) if terms else (repr(front) if kx == 0 else
+                                                  f"{front!r}*cos(theta)" + (f"**{kx}" if kx > 1 else ""))
+            else:
+                fac = [repr(front)]
+                if p2:
+                    fac.append("(" + poly([(float(t.a0[i]), 0), (float(t.a2[i]), 2)]) + ")" + ("" if p2 == 2 else f"**{p2 / 2.0}"))
+                if terms:
+                    fac.append("(" + poly(terms) + ")")
+                am = abs(m)
+                fac.append(("cos" if m > 0 else "sin") + ("(phi)" if am == 1 else f"({am}*phi)"))
+                if kx:
+                    fac.append("cos(theta)" + (f"**{kx}" if kx > 1 else ""))
+                expr = "*".join(fac)
+            name = f"Yl{l}_m{m}".replace("-", "_minus_")
+            lines += ["@torch.jit.script", f"def {name}(theta, phi):", f"    return {expr}", ""]
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+    return path
