@@ -205,23 +205,40 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     return res
 
 
+def csrc_sha256():
+    """SHA-256 over the sources of librange_hip.so (as profiles/make_attend_pmc.py stamps them)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "range_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, B, N, qt, ns):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/attend_pmc.json: a list of entries keyed by kernel and launch geometry).  A static
-    figure from an earlier profiled run of the SAME workload - None when no entry matches."""
+    (profiles/attend_pmc.json, written by tools/profile_bench.sh + profiles/make_attend_pmc.py: entries
+    keyed by kernel and launch geometry and STAMPED with the SHA-256 of the kernel sources they were
+    measured on).  Reported only while this checkout's sources hash to that stamp - counters of other
+    kernels are not this run's traffic - else None with the reason.  Returns (bytes, source, entry)."""
     path = os.path.join(REPO, "profiles", "attend_pmc.json")
     try:
         entries = json.load(open(path))
     except Exception:
-        return None, "no profiles/attend_pmc.json"
+        return None, "no profiles/attend_pmc.json", None
     if isinstance(entries, dict):
         entries = [entries]
+    sha = csrc_sha256()
     for e in entries:
         if (e.get("kernel_key") == kernel and e.get("queries") == B and e.get("bank_rows") == N
                 and e.get("query_tiles") == qt and e.get("bank_splits") == ns):
+            if e.get("csrc_sha256") != sha:
+                return None, (f"profiles/attend_pmc.json was measured on other kernel sources (csrc sha256 "
+                              f"{str(e.get('csrc_sha256'))[:12]}, this checkout {sha[:12]}): re-run tools/profile_bench.sh"), None
             return e.get("hbm_bytes_per_launch"), \
-                f"profiles/attend_pmc.json (static: rocprofv3 --pmc passes of {e.get('source', '?')})"
-    return None, "no PMC entry for this workload/geometry in profiles/attend_pmc.json"
+                f"profiles/attend_pmc.json (rocprofv3 --pmc passes of {e.get('source', '?')}; kernel sources sha256 {sha[:12]} = this checkout)", e
+    return None, "no PMC entry for this workload/geometry in profiles/attend_pmc.json", None
 
 
 def main():
@@ -499,8 +516,8 @@ def main():
             alg_bytes = n_local * BANK_ROW_BYTES + q_per_launch * (1040 + 4096)
         qt, ns = m["geometry"]
         kernel_key = "attend_stored_kernel<true>" if kept else "attend_kernel<true>"
-        traffic, traffic_source = (pmc_traffic(kernel_key, q_per_launch, n_local, qt, ns)
-                                   if not sharded else (None, "not profiled for the sharded layout"))
+        traffic, traffic_source, pmc_entry = (pmc_traffic(kernel_key, q_per_launch, n_local, qt, ns)
+                                              if not sharded else (None, "not profiled for the sharded layout", None))
         step_s = dt / a.steps
         st_flops = q_scanned * n_local * FLOP_PAIR_STATS
         en_flops = B * 2 * (L * L * H + H * H + 256 * H)
@@ -534,6 +551,11 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # all kernels of the step (pass 1 writes the kept logits, pass 2 reads them back), and
+                         # against SURVEY 8(d)'s HBM-minimal one bank pass + per-query I/O
+                         "traffic_per_step": None if pmc_entry is None else pmc_entry.get("hbm_bytes_per_step"),
+                         "traffic_per_step_over_hbm_minimal":
+                             None if pmc_entry is None else pmc_entry.get("hbm_bytes_per_step_over_survey_minimal"),
                          "avg_launch_ms": att_avg_ms, "launches": att_n,
                          "queries_per_launch": q_per_launch,
                          "flop_per_launch": flops,

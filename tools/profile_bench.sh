@@ -22,6 +22,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2 -o p -- $B --steps 3 --warmup 1 > $O/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc3 -o p -- $B --steps 3 --warmup 1 > $O/p3.log 2>&1
 python3 $R/profiles/pmc_summarize.py $O/pmc1 $O/pmc2 $O/pmc3 > $O/pmc_summary.json
+# the traffic figures bench.py reports, stamped with the hash of the kernel sources measured (copy to profiles/attend_pmc.json)
+python3 $R/profiles/make_attend_pmc.py $O/pmc_summary.json $O/bench_line.json $tag > $O/attend_pmc.json
 find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 echo "bench passes done"
 mkdir -p $O/scan
