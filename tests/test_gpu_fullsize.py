@@ -237,3 +237,39 @@ def test_c5_beta_sweep_full_bank(tmp_path):
     assert float(d[:, 2:].max()) < 2e-6 and float(d[:, :2].max()) < 5e-5
     # beta = 1 is the semantic retrieval alone, beta = 0 the geographic one: they differ
     assert float((sw[0] - sw[4]).abs().max()) > 1e-3
+
+
+def test_c5_beta_sweep_one_million_queries(tmp_path):
+    """BASELINE config 5 at its FULL query count on one GPU: 1 000 000 queries x 5 betas over
+    range_db_large (51 GB of float64 results, held in HBM: 288 GB per GPU is what makes that a
+    non-event).  Every one of the 5 x 10^6 rows through the size-independent properties (planted
+    constant columns reproduced iff a row's weights sum to one, value range, unit e-hat, finite),
+    a sample of every beta against the float64 oracle, and the sweep of a slab again, bit for bit."""
+    N, B = synth.BANK_ROWS["range_db_large"], 1_000_000
+    betas = (0.0, 0.25, 0.5, 0.75, 1.0)
+    m, obank, w = _model(tmp_path, N)
+    q = synth.make_queries(B, seed=77)
+    x = torch.from_numpy(q).to("cuda:0")
+    sw = m.sweep(x, betas, return_device=True)
+    assert sw.shape == (len(betas), B, 1280) and sw.dtype == torch.float64 and sw.is_cuda
+    vmin, vmax = float(obank.values.min()), float(obank.values.max())
+    for j, b in enumerate(betas):
+        worst0 = worst1 = 0.0
+        for lo in range(0, B, 100_000):           # (slabs: the reductions' temporaries stay small)
+            s = sw[j, lo:lo + 100_000]
+            assert bool(torch.isfinite(s).all())
+            worst0 = max(worst0, float((s[:, 0] - 1.0).abs().max()))
+            worst1 = max(worst1, float((s[:, 1] + 2.5).abs().max()))
+            assert float(s[:, :1024].max()) <= vmax and float(s[:, :1024].min()) >= vmin
+            assert float((s[:, 1024:].norm(dim=1) - 1.0).abs().max()) < 1e-12
+        assert worst0 < 1e-5 and worst1 < 2.5e-5, (b, worst0, worst1)
+        assert torch.equal(sw[j, :, 1024:], sw[0, :, 1024:])      # e-hat does not depend on beta
+    idx = np.sort(np.random.default_rng(3).choice(B, 32, replace=False))
+    sel = torch.from_numpy(idx).to("cuda:0")
+    for j, b in enumerate(betas):
+        got = sw[j][sel].cpu().numpy()
+        np.testing.assert_allclose(got[:, :1024], O.retrieve64(got[:, 1024:], q[idx], obank, "RANGE+", b), rtol=0, atol=2e-5)
+    # a slab of the job on its own: the same bits (chunks of 16 384 queries: the slab starts on a chunk)
+    lo = 16384 * 7
+    again = m.sweep(x[lo:lo + 16384], betas, return_device=True)
+    assert torch.equal(again, sw[:, lo:lo + 16384])
