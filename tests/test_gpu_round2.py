@@ -510,3 +510,28 @@ def test_fused_topk_counters_survive_many_calls_and_batch_sizes():
         rv, ri = ref_eng.topk_stream(e, 16)
         assert torch.equal(ti, ri) and torch.equal(tv, rv), (i, B)
     eng.check_async_error()
+
+
+def test_topk_stream_on_a_dram_sized_bank():
+    """The scan at the size its roofline entry is quoted on (N = 10^6 keys, 512 MB as bf16: streamed
+    from DRAM, 61 rounds of tiles per wave): indices equal a float64 top-k for 1 .. 5 passes and over
+    supergroups, call after call (the fused tail's ticket counters only count up)."""
+    N = 1_000_000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(N)
+    keys = torch.randn((N, 256), generator=g, device=dev, dtype=torch.float32)
+    cent = torch.randn((32, 256), generator=g, device=dev, dtype=torch.float32)
+    keys += 3.0 * cent[torch.randint(0, 32, (N,), generator=g, device=dev)]
+    keys = torch.nn.functional.normalize(keys, dim=1).contiguous()
+    eng = _native.HipEngine(dev)
+    eng.set_keys(keys)
+    for rep, B in enumerate((16, 1, 40, 32, 130, 64, 16, 256)):
+        e = torch.nn.functional.normalize(
+            keys[torch.randint(0, N, (B,), generator=g, device=dev)] + 0.5 * torch.randn((B, 256), generator=g, device=dev),
+            dim=1).contiguous()
+        tv, ti = eng.topk_stream(e, 16)
+        rv, ri = torch.topk(e.double() @ keys.double().T, 16, dim=1)
+        # (float32 near-ties may swap against float64: at most one query of a batch)
+        assert int((ti != ri).any(dim=1).sum()) <= 1, (rep, B)
+        assert float((tv - rv.float()).abs().max()) < 3e-7
+    eng.check_async_error()
