@@ -401,6 +401,31 @@ def test_sharded_path_over_rccl_world1(tmp_path):
         sw = model.sweep(x, (0.0, 0.5, 1.0)).cpu().numpy()
         for j, b in enumerate((0.0, 0.5, 1.0)):
             np.testing.assert_allclose(sw[j], O.forward(q, w, 10, obank, "RANGE+", b), rtol=0, atol=2e-5)
+        # the product entry and the sharded batch driver over RCCL (device-resident gather to rank 0 on
+        # the copy stream, pinned staging, the byte counters): the code path of a real multi-GPU job
+        from argparse import Namespace
+        from range_amd import load_model
+        from range_amd.save import save_embeddings
+        ck = synth.write_checkpoint(str(tmp_path / "enc.ckpt"), L=10, hidden=64, seed=5)
+        db = synth.write_bank(str(tmp_path / "db.npz"), 900, 3)
+        m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=0.25, shards=1)
+        m1 = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path=db, beta=0.25)
+        qq = synth.make_queries(700, seed=31)
+        full = m(torch.from_numpy(qq))
+        assert isinstance(full, np.ndarray) and full.shape == (700, 1280)
+        np.testing.assert_allclose(full, m1(torch.from_numpy(qq)), rtol=0, atol=2e-6)
+        batches = [(torch.from_numpy(qq[i:i + 128]), torch.arange(len(qq[i:i + 128]))) for i in range(0, 700, 128)]
+        args = Namespace(embeddings_dir=str(tmp_path / "emb"), location_model_name="RANGE+", task_name="rccl")
+        m.sharded.reset_bytes()
+        save_embeddings(args, batches, batches[:2], m)
+        z = np.load(tmp_path / "emb" / "RANGE+" / "rccl_train.npz")
+        assert np.array_equal(z["coords"], qq) and z["embeddings"].shape == (700, 1280)
+        np.testing.assert_allclose(z["embeddings"], full, rtol=0, atol=2e-6)
+        assert m.sharded.bytes_sent["results"] == 0            # (rank 0 receives; with one rank nothing travels)
+        m.sharded.comm_timing(True)
+        m(torch.from_numpy(qq), return_device=True)
+        ms = m.sharded.comm_timing(False)
+        assert set(ms) == {"gather", "reduce", "exchange", "total"} and ms["total"] >= 0.0
     finally:
         dist.destroy_process_group()
 
