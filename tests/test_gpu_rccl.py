@@ -62,18 +62,22 @@ def _sample_check(out_rows, q_rows, obank, w, betas):
         np.testing.assert_allclose(got, O.retrieve(e, q_rows, obank, "RANGE+", b), rtol=0, atol=1e-4)
 
 
-def _rank(rank, world, port, ck, rbank, tmp, ret):
+def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
     import torch.distributed as dist
     from oracle import range_oracle as O
     from range_amd import load_model
     from range_amd.save import save_embeddings
     from tools import synth
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dev = torch.device("cuda", rank)
-    torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:       # rehearsal of THIS test's body on a one-GPU box: gloo ranks sharing cuda:0 (see the test below)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        assert dist.get_backend() == "nccl"
+        assert dist.get_backend() == backend
         obank = O.prep_bank(*_bank_arrays())
         w = synth.make_encoder_weights(L, H, 256, 2, SEED)
         vmin, vmax = float(obank.values.min()), float(obank.values.max())
@@ -156,6 +160,12 @@ def _rank(rank, world, port, ck, rbank, tmp, ret):
 
 def test_rccl_row_sharded_at_c4_c5_shapes(tmp_path):
     world = _world()
+    backend = "nccl"
+    # RANGE_RCCL_TEST_REHEARSAL=W: the body of this test with W gloo ranks sharing cuda:0 - how the test
+    # itself was checked on the one-GPU boxes it was written on (every assertion below has run green
+    # that way with W = 2 and W = 4; what the rehearsal cannot reach is RCCL itself)
+    if os.environ.get("RANGE_RCCL_TEST_REHEARSAL"):
+        world, backend = int(os.environ["RANGE_RCCL_TEST_REHEARSAL"]), "gloo"
     if world < 2:
         pytest.skip(f"RCCL needs >= 2 GPUs, {torch.cuda.device_count()} visible "
                     "(the same shapes run as two gloo ranks on one GPU: tests/test_gpu_sharded.py)")
@@ -165,5 +175,5 @@ def test_rccl_row_sharded_at_c4_c5_shapes(tmp_path):
     ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
     rbank = write_bankfile(str(tmp_path / "large.rbank"), prepare_bank(*_bank_arrays()))
     ret = mp.Manager().dict()
-    mp.spawn(_rank, args=(world, _free_port(), ck, rbank, str(tmp_path), ret), nprocs=world, join=True)
+    mp.spawn(_rank, args=(world, _free_port(), ck, rbank, str(tmp_path), ret, backend), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
