@@ -22,6 +22,7 @@ build; the encoder uses numpy float64.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -128,8 +129,8 @@ class YlmTable:
 
 
 #: the committed fixture with the numbers of the reference's generated functions up to L = 40
-YLM_FIXTURE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
-    __import__("os").path.abspath(__file__))), "tests", "golden", "ylm_table_L40.npz")
+YLM_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           "tests", "golden", "ylm_table_L40.npz")
 
 
 def load_ylm_table(path: str = YLM_FIXTURE) -> YlmTable:
