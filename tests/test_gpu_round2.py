@@ -535,3 +535,64 @@ def test_topk_stream_on_a_dram_sized_bank():
         assert int((ti != ri).any(dim=1).sum()) <= 1, (rep, B)
         assert float((tv - rv.float()).abs().max()) < 3e-7
     eng.check_async_error()
+
+
+def test_scan_stats_at_chunks_share_one_workspace():
+    """range_scan_stats_at (pass 1 in chunks of one scan, range_amd/dist.py): chunks called in order keep
+    their logits at their offsets of ONE workspace - pass 2 on them equals pass 2 behind a single
+    range_scan_stats bit for bit when every chunk uses the same bank splits, and a query's statistics do
+    not depend on the chunking; out of order, or past what the first chunk could keep, nothing is kept
+    but the statistics are still right; bad offsets are refused."""
+    L, H, N, B = 10, 64, 5003, 448
+    w, ws, bs = _weights(L, H, 2, 9)
+    locs, vals, keys = synth.make_bank(N, 4)
+    bank = prepare_bank(locs, vals, keys)
+    eng = _native.HipEngine("cuda:0")
+    eng.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    eng.set_bank(bank.keys, bank.values, bank.xyz)
+    x = torch.from_numpy(synth.make_queries(B, seed=2)).cuda()
+    e64, e32, xq = eng.encode(x)
+    S = eng.p1_splits(192)
+    assert S >= 1
+    # one call over everything, with the chunks' split count
+    st_all = eng.scan_stats_at(e32, xq, 12.0, 40.0, 0, B, n_splits=S)
+    assert eng.kept_queries() == B
+    # three chunks (192 + 128 + 128 queries); pass 2 runs per chunk in both cases (its own split count
+    # follows its launch's geometry, so it is compared chunk by chunk)
+    cuts = [(0, 192), (192, 320), (320, 448)]
+    ref = torch.cat([eng.attend_kept(lo, xq[lo:hi].contiguous(), 12.0, 40.0, 0.5, st_all[lo:hi].contiguous()) for lo, hi in cuts])
+    sts = [eng.scan_stats_at(e32[lo:hi].contiguous(), xq[lo:hi].contiguous(), 12.0, 40.0, lo, B, n_splits=S)
+           for lo, hi in cuts]
+    assert eng.kept_queries() == B
+    st = torch.cat(sts)
+    assert torch.equal(st, st_all)                                         # a query's statistics: chunking-free
+    out = torch.cat([eng.attend_kept(lo, xq[lo:hi].contiguous(), 12.0, 40.0, 0.5, st[lo:hi].contiguous()) for lo, hi in cuts])
+    assert torch.equal(out, ref)
+    # ... and equal to recomputing the logits (range_attend), as ever
+    rec = torch.cat([eng.attend(e32[lo:hi].contiguous(), xq[lo:hi].contiguous(), 12.0, 40.0, 0.5, st_all[lo:hi].contiguous())
+                     for lo, hi in cuts])
+    assert torch.equal(rec, ref)
+    # out of order: a later chunk without the first - statistics right, nothing kept
+    eng.scan_stats(e32[:64].contiguous(), xq[:64].contiguous(), 12.0, 40.0)                  # (forgets the scan)
+    s2 = eng.scan_stats_at(e32[192:320].contiguous(), xq[192:320].contiguous(), 12.0, 40.0, 192, B, n_splits=S)
+    assert eng.kept_queries() == 0 and torch.equal(s2, st_all[192:320])
+    with pytest.raises(_native.RangeNativeError, match="kept"):
+        eng.attend_kept(192, xq[192:320].contiguous(), 12.0, 40.0, 0.5, s2)
+    # a scan restarted with another total is a new scan
+    eng.scan_stats_at(e32[:192].contiguous(), xq[:192].contiguous(), 12.0, 40.0, 0, 192, n_splits=S)
+    assert eng.kept_queries() == 192
+    eng.scan_stats_at(e32[192:320].contiguous(), xq[192:320].contiguous(), 12.0, 40.0, 192, B, n_splits=S)
+    assert eng.kept_queries() == 0
+    for first, total in ((32, B), (-64, B), (384, 400)):                   # not a tile boundary / negative / past the scan
+        with pytest.raises(_native.RangeNativeError):
+            eng.scan_stats_at(e32[:64].contiguous(), xq[:64].contiguous(), 12.0, 40.0, first, total)
+    # a context that never keeps (RANGE_KEEP_LOGITS=0): statistics only
+    os.environ["RANGE_KEEP_LOGITS"] = "0"
+    try:
+        nk = _native.HipEngine("cuda:0")
+    finally:
+        os.environ.pop("RANGE_KEEP_LOGITS", None)
+    nk.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, ws, bs)
+    nk.set_bank(bank.keys, bank.values, bank.xyz)
+    s3 = nk.scan_stats_at(e32, xq, 12.0, 40.0, 0, B, n_splits=S)
+    assert nk.kept_queries() == 0 and torch.equal(s3, st_all)
