@@ -139,6 +139,44 @@ inline void recurrence_tables(int L, bool analytic, std::vector<double>& coefA, 
     }
 }
 
+// The hidden width the encoder kernels run a checkpoint's `capacity` at: kernels exist for multiples
+// of 64 up to 512, and for 768 and 1024; any other width up to 1024 runs as the next of those with
+// zero-padded weights (a padded unit is sin(w0 (0 . x + 0)) = 0 feeding zero weights: every product
+// it adds is an exact +0.0, the unpadded network's result bit for bit).  0: unsupported.
+inline int kernel_hidden_width(int hidden) {
+    if (hidden < 1 || hidden > 1024) return 0;
+    return hidden <= 512 ? (hidden + 63) / 64 * 64 : (hidden <= 768 ? 768 : 1024);
+}
+
+// (n_out x k_in) row-major -> (n_pad x k_pad), the new rows and columns zero
+inline std::vector<double> pad_weights(const double* W, int n_out, int k_in, int n_pad, int k_pad) {
+    std::vector<double> P((size_t)n_pad * k_pad, 0.0);
+    for (int r = 0; r < n_out; ++r)
+        std::copy(W + (size_t)r * k_in, W + (size_t)(r + 1) * k_in, P.begin() + (size_t)r * k_pad);
+    return P;
+}
+
+// Query ranges of the numpy contract's pass 2 (range_forward_host): the batch in parts, the tail parts
+// of the given nominal sizes (the last ones shortest: their copies are what the caller waits for), cuts
+// rounded UP to a query tile, never past the batch and never backwards - whatever `tail` holds
+// (RANGE_HOST_PARTS).  Returns the cut positions, first 0 and last B.
+inline std::vector<int64_t> host_part_cuts(int64_t B, const std::vector<int64_t>& tail, int64_t tile) {
+    std::vector<int64_t> cuts{0};
+    int64_t rest = 0;
+    for (auto v : tail) rest += v;
+    if (rest < B) {
+        int64_t at = B - rest;
+        for (auto v : tail) {
+            const int64_t cut = std::min<int64_t>(B, (at + tile - 1) / tile * tile);
+            if (cut > cuts.back()) cuts.push_back(cut);
+            at += v;
+        }
+        if (cuts.back() == B) cuts.pop_back();
+    }
+    cuts.push_back(B);
+    return cuts;
+}
+
 // Weights (n_out, k_in) row-major -> MFMA B-fragment order, two k-steps per 16-byte lane element:
 //   [((ntile*kpairs + kpair)*64 + lane)*2 + e] = W[ntile*16 + (lane&15)][kperm[kpair*8 + 4e + (lane>>4)]]
 // (kperm: padded position -> column or -1 for a zero pad; null: identity).

@@ -547,13 +547,10 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
     if (!c || !d || !weights || !biases) return fail(RANGE_ERR_INVALID, "null argument");
     const int L = d->legendre_polys, Hc = d->hidden, NL = d->num_hidden_layers, E = d->embed_dim;
     if (L < 1 || L > 64) return fail(RANGE_ERR_INVALID, "legendre_polys %d unsupported (1..64)", L);
-    if (Hc < 1 || Hc > 1024) return fail(RANGE_ERR_INVALID, "hidden %d unsupported (1..1024)", Hc);
-    // The kernels exist for hidden widths that are multiples of 64 up to 512, and 768 and 1024.  Any
-    // other width of the checkpoint (`capacity` of the real one is unknown) runs as the next of those
-    // with ZERO-PADDED weights: a padded hidden unit is sin(w0 (0 . x + 0)) = 0 and feeds zero weights,
-    // every product it adds is an exact +0.0 - the result is the unpadded network's, bit for bit in
-    // the same summation order, at the padded width's cost.
-    const int H = Hc <= 512 ? (Hc + 63) / 64 * 64 : (Hc <= 768 ? 768 : 1024);
+    // (`capacity` of the real checkpoint is unknown: a width no kernel exists for runs zero-padded as
+    // the next one that has - host_plan.h: kernel_hidden_width - at the padded width's cost)
+    const int H = kernel_hidden_width(Hc);
+    if (H == 0) return fail(RANGE_ERR_INVALID, "hidden %d unsupported (1..1024)", Hc);
     if (NL < 1 || NL + 1 > ENC_MAX_LAYERS) return fail(RANGE_ERR_INVALID, "num_hidden_layers %d unsupported", NL);
     if (E != ENC_EMBED) return fail(RANGE_ERR_INVALID, "embed_dim %d unsupported (must be 256)", E);
     if (d->sh_mode != RANGE_SH_ANALYTIC && d->sh_mode != RANGE_SH_CLOSED_FORM)
@@ -578,12 +575,7 @@ int range_set_encoder(range_ctx* c, const range_encoder_desc* d, const double* c
         return pack_weights(W, n_out, k_in, kperm, Kpad);
     };
     for (int i = 0; i <= NL; ++i) if (!weights[i] || !biases[i]) return fail(RANGE_ERR_INVALID, "weights[%d]/biases[%d] null", i, i);
-    // (n_out x k_in) of the checkpoint -> (n_pad x k_pad), the new rows and columns zero
-    auto padded = [](const double* W, int n_out, int k_in, int n_pad, int k_pad) {
-        std::vector<double> P((size_t)n_pad * k_pad, 0.0);
-        for (int r = 0; r < n_out; ++r) std::copy(W + (size_t)r * k_in, W + (size_t)(r + 1) * k_in, P.begin() + (size_t)r * k_pad);
-        return P;
-    };
+    auto padded = [](const double* W, int n_out, int k_in, int n_pad, int k_pad) { return pad_weights(W, n_out, k_in, n_pad, k_pad); };
     if (H == Hc) {
         HIP_TRY(c->d_wp[0].upload(pack(weights[0], H, L * L, &perm, Kp)));
         for (int i = 1; i < NL; ++i) HIP_TRY(c->d_wp[i].upload(pack(weights[i], H, H, nullptr, H)));
@@ -1665,7 +1657,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     // chip (8 query tiles x 32 bank splits, 64 x 4: exactly one round) - measured for 10 000 queries,
     // medians of 30 calls (tools/host_parts.py; the box wanders by +-0.1 ms): (4 096, 512) 19.71 ms,
     // (2 048, 256) 19.70, (3 072, 512) 19.87, (4 096, 1 024) 19.96, (1 792, 256) 19.98.
-    std::vector<int64_t> cuts{0};
+    std::vector<int64_t> cuts{0, B};
     if (B >= 4096) {
         // RANGE_HOST_PARTS="2048,512": sizes of the parts behind the first (tuning)
         std::vector<int64_t> tail{4096, 512};
@@ -1679,21 +1671,8 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
                 q = *end ? end + 1 : end;
             }
         }
-        int64_t rest = 0;
-        for (auto v : tail) rest += v;
-        if (rest < B) {
-            int64_t at = B - rest;
-            // (cuts rounded UP to a query tile: the last part is at most its nominal size, whole slabs;
-            // never past the batch and never backwards, whatever RANGE_HOST_PARTS holds)
-            for (auto v : tail) {
-                const int64_t cut = std::min<int64_t>(B, (at + QTILE - 1) / QTILE * QTILE);
-                if (cut > cuts.back()) cuts.push_back(cut);
-                at += v;
-            }
-            if (cuts.back() == B) cuts.pop_back();
-        }
+        cuts = host_part_cuts(B, tail, QTILE);       // (host_plan.h: rounded up to a tile, clamped, monotonic)
     }
-    cuts.push_back(B);
     constexpr int64_t SLAB = 1024;
     struct Slab { int64_t q0, nq; hipEvent_t fin, cop; };
     std::vector<Slab> slabs;

@@ -134,7 +134,41 @@ static void test_copy_pool() {
     }
 }
 
+// hidden widths without a kernel run zero-padded as the next width that has one; the cuts of the
+// numpy contract stay inside the batch whatever RANGE_HOST_PARTS holds
+static void test_padding_and_host_parts() {
+    for (int h = -3; h <= 1100; ++h) {
+        const int k = kernel_hidden_width(h);
+        if (h < 1 || h > 1024) { CHECK(k == 0); continue; }
+        CHECK(k >= h && (k == 768 || k == 1024 || (k <= 512 && k % 64 == 0)));
+        CHECK(k - h < 256 && (h % 64 != 0 || h > 512 || k == h) && kernel_hidden_width(k) == k);
+    }
+    std::mt19937_64 rng(11);
+    for (int trial = 0; trial < 50; ++trial) {
+        const int n = 1 + (int)(rng() % 70), kin = 1 + (int)(rng() % 90), np = n + (int)(rng() % 40), kp = kin + (int)(rng() % 40);
+        std::vector<double> W((size_t)n * kin);
+        for (auto& v : W) v = (double)(rng() % 9973) + 1.0;
+        const std::vector<double> P = pad_weights(W.data(), n, kin, np, kp);
+        CHECK(P.size() == (size_t)np * kp);
+        for (int r = 0; r < np; ++r)
+            for (int c = 0; c < kp; ++c)
+                CHECK(P[(size_t)r * kp + c] == (r < n && c < kin ? W[(size_t)r * kin + c] : 0.0));
+    }
+    const std::vector<std::vector<int64_t>> tails = {{4096, 512}, {4096, 1}, {1}, {64}, {5000, 5000, 5000}, {100000}, {}, {63, 63, 63},
+                                                     {2048, 256}, {1, 1, 1, 1}};
+    for (int64_t B : {(int64_t)4096, (int64_t)4097, (int64_t)10000, (int64_t)16384, (int64_t)5000})
+        for (const auto& t : tails) {
+            const std::vector<int64_t> cuts = host_part_cuts(B, t, 64);
+            CHECK(cuts.size() >= 2 && cuts.front() == 0 && cuts.back() == B);
+            for (size_t i = 1; i < cuts.size(); ++i) CHECK(cuts[i] > cuts[i - 1]);
+            for (size_t i = 1; i + 1 < cuts.size(); ++i) CHECK(cuts[i] % 64 == 0 && cuts[i] < B);
+        }
+    const std::vector<int64_t> d = host_part_cuts(10000, {4096, 512}, 64);          // the default of range_forward_host
+    CHECK(d.size() == 4 && d[1] == 5440 && d[2] == 9536);
+}
+
 int main() {
+    test_padding_and_host_parts();
     test_plan_and_packing();
     test_choose_splits();
     test_encoder_split();
