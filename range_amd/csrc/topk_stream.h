@@ -268,8 +268,12 @@ __device__ __forceinline__ void topk_qwait(f32x4 (&d)[16]) {
 // first tiles meanwhile (its LDS is not touched here).
 template <int L>
 __device__ __forceinline__ void topks_publish(ShortList<L> (&lists)[TOPKS_SG], int sg, const TopkStreamArgs& a,
-                                              char* smem, int lane, int wave, bool more) {
+                                              char* smem, int lane, int wave, bool more,
+                                              unsigned long long* ts = nullptr) {
     static_assert(L == 4 && TOPKS_WL == 8, "merge4_lists4_top8");
+    // (stamp builds: ts[0] += lane merges + LDS stores, ts[1] += the wait at the barrier, ts[2] += the
+    // workgroup merge, its stores and the second barrier)
+    const unsigned long long ts_p0 = RANGE_TS_NOW();
     unsigned long long* wl = reinterpret_cast<unsigned long long*>(smem + TOPKS_RING_BYTES);
     float* wd = reinterpret_cast<float*>(smem + TOPKS_RING_BYTES + TOPKS_XL_BYTES);
     const int g = lane >> 4, j = lane & 15;
@@ -293,7 +297,9 @@ __device__ __forceinline__ void topks_publish(ShortList<L> (&lists)[TOPKS_SG], i
             }
         }
     }
+    const unsigned long long ts_p1 = RANGE_TS_NOW();
     __syncthreads();
+    const unsigned long long ts_p2 = RANGE_TS_NOW();
     const int grp = sg * TOPKS_SG + wave;
     if (grp < a.n_groups) {
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(wl + ((wave * 4 + g) * 16 + j) * TOPKS_WL);
@@ -311,6 +317,11 @@ __device__ __forceinline__ void topks_publish(ShortList<L> (&lists)[TOPKS_SG], i
         }
     }
     if (more) __syncthreads();       // (the list area is written again at the end of the next supergroup)
+#ifdef RANGE_EXP_TS_STAMPS
+    if (ts) { ts[0] += ts_p1 - ts_p0; ts[1] += ts_p2 - ts_p1; ts[2] += RANGE_TS_NOW() - ts_p2; }
+#else
+    (void)ts; (void)ts_p0; (void)ts_p1; (void)ts_p2;
+#endif
 }
 
 template <int L>
@@ -731,6 +742,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream_bf16_kernel(TopkStreamArgs
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
     const uint32_t n_valid32 = (uint32_t)a.n_valid;
+    unsigned long long ts_pub[3] = {0ull, 0ull, 0ull};       // (stamp builds: where the publishes' time goes)
 
     int k = 0;
     for (int sg = 0; sg < n_sg; ++sg) {
@@ -832,9 +844,15 @@ __global__ __launch_bounds__(256, 1) void topk_stream_bf16_kernel(TopkStreamArgs
             }
         }
         RANGE_TS_STAMP(4);   // all tiles of the supergroup consumed
-        topks_publish<L>(lists, sg, a, smem, lane, wave, sg + 1 < n_sg);
+        topks_publish<L>(lists, sg, a, smem, lane, wave, sg + 1 < n_sg, ts_pub);
     }
     RANGE_TS_STAMP(5);
+#ifdef RANGE_EXP_TS_STAMPS
+    if (lane == 0 && a.stamps) {   // sums over the supergroups' publishes: lane merges / barrier wait / workgroup merge
+        a.stamps[(size_t)w_id * 8 + 3] = ts_pub[1];
+        a.stamps[(size_t)w_id * 8 + 7] = (ts_pub[0] << 32) | (ts_pub[2] & 0xFFFFFFFFull);
+    }
+#endif
     topks_tail(a, smem);
 }
 
