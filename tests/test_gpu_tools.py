@@ -43,3 +43,20 @@ def test_validate_real_widths_between_the_kernels_and_beyond(tmp_path):
     ck = synth.write_checkpoint(str(tmp_path / "e1088.ckpt"), L=10, hidden=1088, seed=4)
     r = _run(ck, db)
     assert r.returncode == 2 and "UNSUPPORTED" in r.stderr and "1024" in r.stderr, r.stdout + r.stderr
+
+
+def test_c_abi_from_a_plain_program(tmp_path):
+    """librange_hip.so from a program without Python or torch (tests/native/abi_smoke.cpp): hipMalloc'ed
+    buffers, its own stream, status codes and range_last_error - the boundary as a maintainer of another
+    host language would bind it."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.join(REPO, "range_amd")
+    b = subprocess.run(["hipcc", "-O1", "-std=c++17", "-o", exe, os.path.join(REPO, "tests", "native", "abi_smoke.cpp"),
+                        "-I" + os.path.join(REPO, "include"), "-L" + lib_dir, "-lrange_hip", "-Wl,-rpath," + lib_dir],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
