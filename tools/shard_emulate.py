@@ -38,8 +38,6 @@ LAYOUTS_W = int(sys.argv[sys.argv.index("--layouts") + 1]) if "--layouts" in sys
 if LAYOUTS_W:
     del sys.argv[sys.argv.index("--layouts"):sys.argv.index("--layouts") + 2]
 worlds = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1, 2, 4, 8]
-if "--unchunked-pass1" in sys.argv:
-    pass
 base = {}
 # (mode, ranks in total, row shards R): a rank scans R x its own queries against 100 000 / R rows
 cases = [(mode, W, W) for mode in ("strong", "weak") for W in worlds]
