@@ -1132,6 +1132,12 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
+#ifdef RANGE_EXP_P2_STAMPS
+    // timing build: s_memtime (shader clocks) / s_memrealtime (100 MHz) at entry, loop start, loop
+    // end, stores issued, stores done + the CU this workgroup ran on (tools/pass2_stamps.py)
+    unsigned long long st_c[5], st_r[5];
+    st_c[0] = stamp(); st_r[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     int split, qt;
     decode_block(a, split, qt);
     const int b0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
@@ -1201,6 +1207,9 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
     carry.v0a = carry.v1a = carry.v0b = carry.v1b = f32x4{0.f, 0.f, 0.f, 0.f};
     carry.w0 = carry.w1 = 0.f;
     const int b_last = b1 - 1;
+#ifdef RANGE_EXP_P2_STAMPS
+    st_c[1] = stamp(); st_r[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < nb; ++t) {
         const int vs1 = vs == 2 ? 0 : vs + 1;
         const int vs2 = vs1 == 2 ? 0 : vs1 + 1;
@@ -1287,6 +1296,9 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
     if (nb > 0) pv_exec_carry(acc, carry);   // last step of the last half
     // the clamped prefetches of the last iterations are still in flight into this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RANGE_EXP_P2_STAMPS
+    st_c[2] = stamp(); st_r[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     acc_fence(acc);
     // accumulator tile 4T+c, register r, lane (j,g)  ->  out[query 4g+r of this wave][64T + 4j + c]
@@ -1304,6 +1316,19 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
             }
         }
     }
+#ifdef RANGE_EXP_P2_STAMPS
+    st_c[3] = stamp(); st_r[3] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_c[4] = stamp(); st_r[4] = __builtin_amdgcn_s_memrealtime();
+    if (a.diag && threadIdx.x == 0) {
+        unsigned long long* d = a.diag + (size_t)blockIdx.x * 16;
+        for (int i = 0; i < 5; ++i) { d[i] = st_c[i]; d[5 + i] = st_r[i]; }
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[10] = hw; d[11] = xcc & 0xf; d[12] = (unsigned long long)nb; d[13] = (unsigned long long)split; d[14] = (unsigned long long)qt;
+    }
+#endif
 }
 
 

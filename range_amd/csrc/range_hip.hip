@@ -93,6 +93,7 @@ struct range_ctx {
     uint32_t topk_sync_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the counters read when the next fused launch starts
     bool debug_giveup_next = false;          // range_debug_raise_async_error: the next persistent launch gives up
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
+    int p2_splits_forced = 0;                // RANGE_P2_SPLITS=n: pass 2 with n bank splits (tuning)
     bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 32 queries take the two-pass kernels too (A/B)
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
     DevBuf<uint32_t> ws_read_sink;           // range_stream_read_timed: one word per workgroup
@@ -457,6 +458,7 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
                        : choose_splits(a.n_qtiles, a.n_blocks, c->n_cu, 1,
                                        std::max(32, std::min(512, (c->n_cu + a.n_qtiles - 1) / a.n_qtiles)),
                                        std::max(0.001, 140.0 / (double)c->n_rows));
+    if (!pass1 && c->p2_splits_forced > 0) a.n_splits = std::max(1, std::min(c->p2_splits_forced, std::max(1, a.n_blocks / 4)));
     a.k_sem = (float)(tau_sem * LOG2E);
     a.k_geo = tau_geo > 0.f ? (float)(tau_geo * LOG2E) : 0.f;
     a.beta = 1.f;
@@ -514,6 +516,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
     if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_SMALL_FORWARD")) c->small_forward = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_P2_SPLITS")) c->p2_splits_forced = std::max(0, std::atoi(e));
     {
         DeviceGuard g(device);
         void* hp = nullptr;
@@ -1388,7 +1391,23 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
         } else if (geo) {
             rc = set_dyn_lds(attend_stored_kernel<true>, ATTEND_STORED_LDS_BYTES);
             if (rc) return rc;
+#ifdef RANGE_EXP_P2_STAMPS
+            static DevBuf<unsigned long long> p2_stamps;
+            const char* stamp_file = std::getenv("RANGE_P2_STAMPS");
+            if (stamp_file) {
+                HIP_TRY(p2_stamps.ensure((size_t)grid.x * 16));
+                a.diag = p2_stamps.p;
+            }
+#endif
             hipLaunchKernelGGL(attend_stored_kernel<true>, grid, block, ATTEND_STORED_LDS_BYTES, s, a);
+#ifdef RANGE_EXP_P2_STAMPS
+            if (stamp_file) {
+                std::vector<unsigned long long> h((size_t)grid.x * 16);
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h.data(), p2_stamps.p, h.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(stamp_file, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+            }
+#endif
         } else {
             rc = set_dyn_lds(attend_stored_kernel<false>, ATTEND_STORED_LDS_BYTES);
             if (rc) return rc;

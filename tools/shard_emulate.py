@@ -14,7 +14,10 @@ query - comes on top; DESIGN.md section 6 prices it).
 row-sharded over R ranks, Q = W / R such groups each serving its own queries): a rank holds 100 000 / R
 rows, encodes 10 000 / W queries and scans the 10 000 / Q queries of its group.
 --unchunked-pass1: one pass 1 over all scanned queries (the schedule before round 4), for A/B.
-Usage: python tools/shard_emulate.py [--json] [--chunks k] [--layouts W] [--unchunked-pass1] [N ...]"""
+--cold: the protocol of rounds 2-4 (2 warm-up steps, 5 timed): a rank's 3 ms steps are then timed while
+the chip is still raising its clock after idling (round 5, tools/clock_ramp.py: the first ~35 ms of
+activity run up to 25 % slower) - the default now warms up for >= 150 ms and times 40 steps.
+Usage: python tools/shard_emulate.py [--json] [--cold] [--chunks k] [--layouts W] [--unchunked-pass1] [N ...]"""
 import json
 import os
 import sys
@@ -87,18 +90,31 @@ for mode, WT, W in cases:                                       # W = ranks of a
                 outs.append(eng.finalize(part.reshape(W, hi - lo, 1024), e64[lo:hi].contiguous()))
             return outs
 
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
+        COLD = "--cold" in sys.argv
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if COLD:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            n_steps = 5
+        else:
+            # steady state: the chip raises its clock over the first ~35 ms of activity after idling
+            a.record()
+            step()
+            b.record()
+            b.synchronize()
+            for _ in range(int(150.0 / max(a.elapsed_time(b), 0.1)) + 1):
+                step()
+            n_steps = 40
         eng.profile_enable(True)
         a.record()
-        for _ in range(5):
+        for _ in range(n_steps):
             step()
         b.record()
         b.synchronize()
-        ms = a.elapsed_time(b) / 5
-        k = {nm: round(eng.profile_read(i)[0] / 5, 3) for i, nm in enumerate(["encoder", "scan_stats", "attend"])}
+        ms = a.elapsed_time(b) / n_steps
+        k = {nm: round(eng.profile_read(i)[0] / n_steps, 3) for i, nm in enumerate(["encoder", "scan_stats", "attend"])}
+        eng.profile_enable(False)
         qt, ns = eng.last_geometry()
         if WT == 1:
             base[mode] = ms
