@@ -82,7 +82,57 @@ struct ScanArgs {
     // row subsets, so the 16th largest of a query's entries bounds its 16th best similarity from
     // below (the threshold of topk_from_logits_kernel)
     float* rowmax;
+    // pass 2, stream-K decomposition (round 5): > 0 = the launch has exactly this many workgroups, each
+    // walking a contiguous range of (query tile, bank block) units per bank column (SlabMap below);
+    // 0 = one workgroup per (bank split, query tile) item (decode_block: the bf16-plane kernel, the
+    // diagnostic launches)
+    int32_t sk_groups;
+    int32_t sk_cols;       // bank columns of the stream-K walk (>= 1)
 };
+
+// Where pass 2 leaves its partial outputs, and how their consumers find the parts of a query.
+//   split-major (sk_groups == 0): n_parts planes of (B, 1024): part p of query q at (p B + q) 1024.
+//   stream-K    (sk_groups  > 0): the bank's blocks are cut into sk_cols COLUMNS (contiguous, near-
+//     equal: column c = blocks [c n_blocks / C, (c+1) n_blocks / C)), visited one after the other by
+//     ALL workgroups - a column's rows (the values above all: 4 KB per row) are then re-read by the
+//     workgroups while they are in the Infinity Cache; one column for a bank or shard that fits it.
+//     Inside a column the units u = qtile * column_blocks + block, qtile-major, are cut into
+//     sk_groups contiguous, near-equal ranges [start(w), start(w+1)), start(w) = floor(w U / G):
+//     workgroup w walks its range in order - at most the tail of one query tile, whole tiles, the head
+//     of another - and writes one (64, 1024) slab per query tile it touches, slab index
+//     c (G + n_qtiles) + w + qtile (unique: every next segment of the walk increases w or qtile).
+//     The parts of query tile qt in column c are the slabs w + qt for w = owner(qt cb) ..
+//     owner((qt + 1) cb - 1), in block order; owner(u) = floor(((u + 1) G - 1) / U).  With G = the CUs
+//     every workgroup has the same work (+- one block per column): no last partial round,
+//     C (G + n_qtiles) slabs instead of n_splits n_qtiles, and a workgroup's fixed costs (~7.5 us:
+//     first tiles, 256 KB of stores, dispatch) paid 1-2 times per CU and column.
+struct SlabMap {
+    int32_t n_parts;      // split-major: planes
+    int32_t sk_groups;    // stream-K: workgroups of the launch (0 = split-major)
+    int32_t n_blocks;
+    int32_t n_qtiles;
+    int32_t sk_cols;
+};
+__host__ __device__ __forceinline__ int64_t sk_start(int64_t w, int64_t U, int64_t G) { return (w * U) / G; }
+__host__ __device__ __forceinline__ int64_t sk_owner(int64_t u, int64_t U, int64_t G) { return ((u + 1) * G - 1) / U; }
+__host__ __device__ __forceinline__ int sk_col_begin(int c, int n_blocks, int n_cols) { return (int)(((int64_t)c * n_blocks) / n_cols); }
+// parts of query q in column c (split-major: the one "column" holds all planes): float4 index of the
+// first, the stride between parts and their number
+__device__ __forceinline__ void slab_parts(const SlabMap& m, int64_t B, int64_t q, int c, int64_t& first4, int64_t& stride4, int& count) {
+    if (m.sk_groups == 0) {
+        first4 = q * (VAL_DIM / 4);
+        stride4 = B * (VAL_DIM / 4);
+        count = m.n_parts;
+        return;
+    }
+    const int64_t cb = sk_col_begin(c + 1, m.n_blocks, m.sk_cols) - sk_col_begin(c, m.n_blocks, m.sk_cols);
+    const int64_t qt = q / QTILE, U = (int64_t)m.n_qtiles * cb;
+    const int64_t w0 = sk_owner(qt * cb, U, m.sk_groups), w1 = sk_owner((qt + 1) * cb - 1, U, m.sk_groups);
+    first4 = (((int64_t)c * (m.sk_groups + m.n_qtiles) + w0 + qt) * QTILE + (q - qt * QTILE)) * (VAL_DIM / 4);
+    stride4 = (int64_t)QTILE * (VAL_DIM / 4);
+    count = (int)(w1 - w0) + 1;
+}
+__device__ __forceinline__ int slab_cols(const SlabMap& m) { return m.sk_groups == 0 ? 1 : m.sk_cols; }
 
 // float offset of the kept-logit tile of (query tile, bank block, wave)
 __device__ __forceinline__ int64_t logit_tile(int64_t qtile, int32_t n_blocks, int block, int wave) {
@@ -99,7 +149,11 @@ __device__ __forceinline__ void decode_block(const ScanArgs& a, int& split, int&
     const int b = blockIdx.x;
     const int x = b & 7, j = b >> 3;
     const int q = total >> 3, r = total & 7;
+#ifdef RANGE_EXP_P2_SCATTER     // timing experiment: workgroups of an XCD on unrelated splits (no sharing of V in its L2)
+    const int item = (int)(((int64_t)b * 997) % total);
+#else
     const int item = x * q + (x < r ? x : r) + j;
+#endif
     split = item / a.n_qtiles;
     qt = item - split * a.n_qtiles;
 }
@@ -892,6 +946,57 @@ __device__ __forceinline__ void acc_fence(f32x4 (&acc)[64]) {
                           "+a"(acc[i + 12]), "+a"(acc[i + 13]), "+a"(acc[i + 14]), "+a"(acc[i + 15]));
 }
 
+// The segments of this workgroup (pass 2): one (split, query tile) item, or the walk of a stream-K
+// range.  next() yields the query tile, its block range [b0, b1) and the (64, 1024) tile of the slab
+// the partial goes to.  Everything here is wave-uniform (blockIdx only).
+struct SegWalk {
+    int64_t u, u_end;
+    int split, col, cb0, cb;       // split-major: the item's split; stream-K: column, its first block / block count
+    __device__ __forceinline__ void init(const ScanArgs& a) {
+        col = -1;
+        u = u_end = 0;
+        cb0 = 0;
+        cb = a.n_blocks;
+        split = 0;
+        if (a.sk_groups == 0) {
+            int qt;
+            decode_block(a, split, qt);
+            const int b0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
+            const int b1 = (int)(((int64_t)(split + 1) * a.n_blocks) / a.n_splits);
+            u = (int64_t)qt * a.n_blocks + b0;
+            u_end = u + (b1 - b0);
+        }
+    }
+    __device__ __forceinline__ bool next(const ScanArgs& a, int& qt, int& b0, int& b1, float*& out_tile) {
+        if (a.sk_groups == 0) {
+            if (u >= u_end) return false;
+            qt = (int)(u / a.n_blocks);
+            b0 = (int)(u - (int64_t)qt * a.n_blocks);
+            b1 = b0 + (int)(u_end - u);
+            out_tile = a.out + ((int64_t)split * a.B + (int64_t)qt * QTILE) * VAL_DIM;
+            u = u_end;
+            return true;
+        }
+        while (u >= u_end) {                       // next column
+            if (++col >= a.sk_cols) return false;
+            cb0 = sk_col_begin(col, a.n_blocks, a.sk_cols);
+            cb = sk_col_begin(col + 1, a.n_blocks, a.sk_cols) - cb0;
+            const int64_t U = (int64_t)a.n_qtiles * cb;
+            u = sk_start(blockIdx.x, U, a.sk_groups);
+            u_end = sk_start((int64_t)blockIdx.x + 1, U, a.sk_groups);
+        }
+        qt = (int)(u / cb);
+        const int bo = (int)(u - (int64_t)qt * cb);
+        const int64_t left = u_end - u;
+        const int n = left < (int64_t)(cb - bo) ? (int)left : cb - bo;
+        b0 = cb0 + bo;
+        b1 = b0 + n;
+        out_tile = a.out + ((int64_t)col * (a.sk_groups + a.n_qtiles) + blockIdx.x + qt) * (QTILE * VAL_DIM);
+        u += n;
+        return true;
+    }
+};
+
 // LDS map (bytes): V ring 3 x 32 KB | K ring 2 x 16 KB | X ring 2 x 256 B  = 131,584 B
 constexpr int ATTEND_LDS_BYTES = (3 * 8 * VAL_DIM + 2 * BLK * KEY_DIM + 2 * 64) * 4;
 // pass 1: workgroups per CU (4 = what the 33 KB of LDS allow; fewer by padding the allocation:
@@ -918,10 +1023,13 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
     const int swz = lane ^ (4 * wave);
-    int split, qt;
-    decode_block(a, split, qt);
-    const int b0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
-    const int b1 = (int)(((int64_t)(split + 1) * a.n_blocks) / a.n_splits);
+    SegWalk walk;
+    walk.init(a);
+    int qt, b0, b1;
+    float* out_tile;
+    for (bool first_seg = true; walk.next(a, qt, b0, b1, out_tile); first_seg = false) {
+    // (a later segment re-uses the LDS rings: every wave must be done with the previous one)
+    if (!first_seg) __syncthreads();
     const int nb = b1 - b0;
     const int64_t q = (int64_t)qt * QTILE + wave * 16 + (lane & 15);
 
@@ -1097,7 +1205,7 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
     for (int r = 0; r < 4; ++r) {
         const int64_t qo = qw + 4 * g + r;
         if (qo < a.B) {
-            float* orow = a.out + ((int64_t)split * a.B + qo) * VAL_DIM + 4 * j;
+            float* orow = out_tile + (wave * 16 + 4 * g + r) * VAL_DIM + 4 * j;
 #pragma unroll
             for (int T = 0; T < 16; ++T) {
                 f32x4 o = {acc[4 * T + 0][r], acc[4 * T + 1][r], acc[4 * T + 2][r], acc[4 * T + 3][r]};
@@ -1105,6 +1213,7 @@ __global__ __launch_bounds__(256, 1) void attend_kernel(ScanArgs a) {
             }
         }
     }
+    }   // segments
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,10 +1247,13 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
     unsigned long long st_c[5], st_r[5];
     st_c[0] = stamp(); st_r[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    int split, qt;
-    decode_block(a, split, qt);
-    const int b0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
-    const int b1 = (int)(((int64_t)(split + 1) * a.n_blocks) / a.n_splits);
+    SegWalk walk;
+    walk.init(a);
+    int qt, b0, b1;
+    float* out_tile;
+    for (bool first_seg = true; walk.next(a, qt, b0, b1, out_tile); first_seg = false) {
+    // (a later segment re-uses the LDS rings: every wave must be done with the previous one)
+    if (!first_seg) __syncthreads();
     const int nb = b1 - b0;
     const int64_t q = (int64_t)qt * QTILE + wave * 16 + (lane & 15);
     const int64_t qtile_kept = (int64_t)qt + a.qt_offset;
@@ -1308,7 +1420,7 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
     for (int r = 0; r < 4; ++r) {
         const int64_t qo = qw + 4 * g + r;
         if (qo < a.B) {
-            float* orow = a.out + ((int64_t)split * a.B + qo) * VAL_DIM + 4 * j;
+            float* orow = out_tile + (wave * 16 + 4 * g + r) * VAL_DIM + 4 * j;
 #pragma unroll
             for (int T = 0; T < 16; ++T) {
                 f32x4 o = {acc[4 * T + 0][r], acc[4 * T + 1][r], acc[4 * T + 2][r], acc[4 * T + 3][r]};
@@ -1316,6 +1428,7 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
             }
         }
     }
+    }   // segments
 #ifdef RANGE_EXP_P2_STAMPS
     st_c[3] = stamp(); st_r[3] = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1326,18 +1439,28 @@ __global__ __launch_bounds__(256, 1) void attend_stored_kernel(ScanArgs a) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        d[10] = hw; d[11] = xcc & 0xf; d[12] = (unsigned long long)nb; d[13] = (unsigned long long)split; d[14] = (unsigned long long)qt;
+        d[10] = hw; d[11] = xcc & 0xf; d[12] = (unsigned long long)(a.sk_groups > 0 ? ((int64_t)a.n_qtiles * a.n_blocks) / a.sk_groups : a.n_blocks / a.n_splits);
     }
 #endif
 }
 
 
-// (n_parts, B, 1024) f32 -> (B, 1024) f32, fixed summation order.
-__global__ void reduce_parts_kernel(const float* parts, int n_parts, int64_t total4, float* out) {
+// the parts of pass 2 (SlabMap) -> (B, 1024) f32, fixed summation order (ascending bank blocks).
+__global__ void reduce_parts_kernel(const float* parts, SlabMap m, int64_t B, float* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total4) return;
-    f32x4 s = reinterpret_cast<const f32x4*>(parts)[i];
-    for (int p = 1; p < n_parts; ++p) s += reinterpret_cast<const f32x4*>(parts)[(int64_t)p * total4 + i];
+    if (i >= B * (VAL_DIM / 4)) return;
+    const int64_t q = i / (VAL_DIM / 4);
+    const int c4 = (int)(i - q * (VAL_DIM / 4));
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int col = 0; col < slab_cols(m); ++col) {
+        int64_t first4, stride4;
+        int n;
+        slab_parts(m, B, q, col, first4, stride4, n);
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(parts) + first4 + c4;
+        if (col == 0) s = p4[0];
+#pragma unroll 4   // loads of 4 parts in flight; the additions keep their order
+        for (int p = col == 0 ? 1 : 0; p < n; ++p) s += p4[(int64_t)p * stride4];
+    }
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
@@ -1358,7 +1481,7 @@ __global__ void blend_kernel(const float* G, const float* H, float beta, int64_t
 
 // out (B,1280) f64 = [ sum_p partial_p (f32, widened) | ehat64 ]      (range/range.py:222, :240)
 // for queries [q0, q0 + nq) of a batch of B (parts: (n_parts,B,1024), ehat64 / out: (B,..)).
-__global__ void finalize_kernel(const float* parts, int n_parts, const double* ehat64, int64_t B,
+__global__ void finalize_kernel(const float* parts, SlabMap m, const double* ehat64, int64_t B,
                                 int64_t q0, int64_t nq, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nq * 320 quads
     if (i >= nq * 320) return;
@@ -1366,11 +1489,16 @@ __global__ void finalize_kernel(const float* parts, int n_parts, const double* e
     const int c = (int)(i % 320);
     double* o = out + q * 1280 + 4 * c;
     if (c < 256) {
-        const int64_t off = q * 256 + c;
-        const int64_t stride = B * 256;
-        f32x4 s = reinterpret_cast<const f32x4*>(parts)[off];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int col = 0; col < slab_cols(m); ++col) {
+            int64_t first4, stride4;
+            int n;
+            slab_parts(m, B, q, col, first4, stride4, n);
+            const f32x4* p4 = reinterpret_cast<const f32x4*>(parts) + first4 + c;
+            if (col == 0) s = p4[0];
 #pragma unroll 8   // loads of 8 parts in flight; the additions keep their order
-        for (int p = 1; p < n_parts; ++p) s += reinterpret_cast<const f32x4*>(parts)[(int64_t)p * stride + off];
+            for (int p = col == 0 ? 1 : 0; p < n; ++p) s += p4[(int64_t)p * stride4];
+        }
         o[0] = (double)s.x; o[1] = (double)s.y; o[2] = (double)s.z; o[3] = (double)s.w;
     } else {
         const double* e = ehat64 + q * 256 + 4 * (c - 256);

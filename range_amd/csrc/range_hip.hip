@@ -109,6 +109,9 @@ struct range_ctx {
     uint32_t* d_async_err = nullptr;
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
     int last_qtiles = 0, last_splits = 0;
+    bool p2_streamk = true;         // RANGE_P2_STREAMK=0: pass 2 as one workgroup per (bank split, query tile) (A/B)
+    int p2_col_rows = 16384;        // RANGE_P2_COL_ROWS=n: largest bank column of the stream-K walk (rows; tuning)
+    int p2_streamk_rows = 50000;    // RANGE_P2_STREAMK_ROWS=n: banks / shards up to n rows take the stream-K walk
     // host contract (range_forward_host): device result, pinned staging, copy stream, copy threads
     DevBuf<double> ws_out64;
     void* h_stage = nullptr;
@@ -469,6 +472,8 @@ int fill_scan_args(range_ctx* c, ScanArgs& a, const float* ehat32, const float* 
     a.logits = nullptr;
     a.qt_offset = 0;
     a.rowmax = nullptr;
+    a.sk_groups = 0;
+    a.sk_cols = 1;
     if (!pass1) {
         c->last_qtiles = a.n_qtiles;
         c->last_splits = a.n_splits;
@@ -517,6 +522,9 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_SMALL_FORWARD")) c->small_forward = e[0] != '0';
     if (const char* e = std::getenv("RANGE_P2_SPLITS")) c->p2_splits_forced = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("RANGE_P2_STREAMK")) c->p2_streamk = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_P2_COL_ROWS")) c->p2_col_rows = std::max(64, std::atoi(e));
+    if (const char* e = std::getenv("RANGE_P2_STREAMK_ROWS")) c->p2_streamk_rows = std::max(0, std::atoi(e));
     {
         DeviceGuard g(device);
         void* hp = nullptr;
@@ -1346,7 +1354,7 @@ int range_merge_topk(range_ctx* c, const float* val_parts, const int64_t* idx_pa
 // (attend_stored_kernel; ehat32 is not read); kept_first < 0: recompute the logits.
 static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int64_t B, float tau_sem,
                        float tau_geo, float beta, const float* stats_global, float* partial,
-                       int* n_splits_out, int64_t kept_first, range_stream_t stream) {
+                       SlabMap* map_out, int64_t kept_first, range_stream_t stream) {
     if (!c || (!ehat32 && kept_first < 0) || !xq32 || !stats_global)
         return fail(RANGE_ERR_INVALID, "null argument");
     if (kept_first >= 0) {
@@ -1363,12 +1371,36 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
     int rc = fill_scan_args(c, a, ehat32, xq32, B, tau_sem, tau_geo, false);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c->ws_slabs.ensure((size_t)a.n_splits * B * VAL_DIM));
+    // Stream-K (attend_kernels.h: SlabMap): as many workgroups as CUs, each with the same number of
+    // (query tile, bank block) units (at least 4: tiny launches take fewer workgroups), one slab per
+    // query tile a workgroup touches.  For banks and SHARDS of up to 50 000 rows - measured, 10 000
+    // queries, pass 2 + its reduction, against one workgroup per (split, query tile): 12 500 rows (a
+    // rank of 8) -5.6 %, 25 000 -3.6 %, 50 000 -2.2 %; at 100 000 rows that scheme's 7.97 rounds of
+    // workgroups are 98.5 % full already, the walk gains 0.5-1 % with two 50 000-row columns (and
+    // loses 9 % with one: its workgroups re-read the values from HBM then, not from the Infinity
+    // Cache) while its longer float32 accumulation chains cost accuracy (|sum of weights - 1| of the
+    // worst of 10^5 queries 1.3e-5 instead of 0.5e-5): not taken there.  The exact kernels only;
+    // RANGE_P2_STREAMK=0 / RANGE_P2_SPLITS=n restore the split scheme for A/B.
+    const bool streamk = c->p2_streamk && c->p2_splits_forced == 0 && c->n_rows <= c->p2_streamk_rows &&
+                         !(kept_first >= 0 && c->pv_mode == RANGE_PV_BF16X3);
+    if (streamk) {
+        // columns of at most 16 384 rows: an accumulation chain (one query tile's blocks of a column)
+        // stays within ~2x the 481 blocks of the split scheme on the full bank
+        a.sk_cols = (int32_t)std::max<int64_t>(1, std::min<int64_t>((c->n_rows + c->p2_col_rows - 1) / c->p2_col_rows,
+                                                                    std::max(1, a.n_blocks / 4)));
+        const int64_t Uc = (int64_t)a.n_qtiles * (a.n_blocks / a.sk_cols);     // (units of the shortest column)
+        a.sk_groups = (int32_t)std::max<int64_t>(1, std::min<int64_t>(c->n_cu, Uc / 4));
+        c->last_splits = a.sk_groups;
+        HIP_TRY(c->ws_slabs.ensure((size_t)a.sk_cols * (a.sk_groups + a.n_qtiles) * QTILE * VAL_DIM));
+    } else {
+        HIP_TRY(c->ws_slabs.ensure((size_t)a.n_splits * B * VAL_DIM));
+    }
+    const SlabMap map{a.n_splits, a.sk_groups, a.n_blocks, a.n_qtiles, a.sk_cols};
     a.out = c->ws_slabs.p;
     a.stats = stats_global;
     const bool geo = tau_geo > 0.f;
     a.beta = geo ? beta : 1.f;
-    const dim3 grid((unsigned)(a.n_splits * a.n_qtiles)), block(256);
+    const dim3 grid((unsigned)(streamk ? a.sk_groups : a.n_splits * a.n_qtiles)), block(256);
     if (kept_first >= 0) {
         if (a.n_blocks != c->kept_blocks) return fail(RANGE_ERR_STATE, "bank changed since the logits were kept");
         a.logits = c->ws_logits.p;
@@ -1426,11 +1458,11 @@ static int attend_impl(range_ctx* c, const float* ehat32, const float* xq32, int
         }
     }
     HIP_TRY(hipGetLastError());
-    if (n_splits_out) *n_splits_out = a.n_splits;
+    if (map_out) *map_out = map;
     if (partial) {
         const int64_t total4 = B * (VAL_DIM / 4);
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s,
-                           c->ws_slabs.p, a.n_splits, total4, partial);
+                           c->ws_slabs.p, map, B, partial);
         HIP_TRY(hipGetLastError());
     }
     return RANGE_OK;
@@ -1488,7 +1520,7 @@ int range_finalize(range_ctx* c, const float* partials, int32_t n_parts, const d
     if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const int64_t n = B * 320;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, partials, n_parts, ehat64, B, (int64_t)0, B, out);
+                       (hipStream_t)stream, partials, SlabMap{n_parts, 0, 0, 0, 1}, ehat64, B, (int64_t)0, B, out);
     HIP_TRY(hipGetLastError());
     return RANGE_OK;
 }
@@ -1561,7 +1593,7 @@ static int encode_to_workspace(range_ctx* c, const double* lonlat, int64_t B, ra
 // encode -> pass 1 (keeping its logits) -> pass 2 into the context's split slabs; the caller
 // finalizes (sums the slabs, packs with e-hat).  n_splits_out = number of slabs written.
 static int forward_to_slabs(range_ctx* c, const double* lonlat, int64_t B, int32_t model, float beta,
-                            int* n_splits_out, range_stream_t stream) {
+                            SlabMap* map_out, range_stream_t stream) {
     if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
         return fail(RANGE_ERR_INVALID, "unknown model %d", model);
     if (B <= 0) return fail(RANGE_ERR_INVALID, "B must be > 0");
@@ -1582,7 +1614,7 @@ static int forward_to_slabs(range_ctx* c, const double* lonlat, int64_t B, int32
     if (rc) return rc;
     // pass 2 consumes the logits pass 1 kept (recomputes them if they did not fit in memory)
     return attend_impl(c, c->ws_ehat32.p, c->ws_xq.p, B, tau_sem, tau_geo,
-                       model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, n_splits_out,
+                       model == RANGE_MODEL_RANGE ? 1.0f : beta, c->ws_stats.p, nullptr, map_out,
                        c->kept_B == B ? 0 : -1, stream);
 }
 
@@ -1601,10 +1633,15 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     }
     // single GPU: the finalize kernel sums the split slabs itself (same fixed order as
     // reduce_parts_kernel, so the result is bit-identical to attend + finalize)
-    int n_splits = 0;
-    int rc = forward_to_slabs(c, lonlat, B, model, beta, &n_splits, stream);
+    SlabMap map{};
+    int rc = forward_to_slabs(c, lonlat, B, model, beta, &map, stream);
     if (rc) return rc;
-    return range_finalize(c, c->ws_slabs.p, n_splits, c->ws_ehat64.p, B, out, stream);
+    DeviceGuard g(c->device);
+    const int64_t n = B * 320;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c->ws_slabs.p, map, c->ws_ehat64.p, B, (int64_t)0, B, out);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
 }
 
 int range_host_copy(range_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -1700,9 +1737,9 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     for (size_t part = 0; part + 1 < cuts.size() && e == hipSuccess; ++part) {
         const int64_t p0 = cuts[part], p1 = cuts[part + 1];
         if (p1 <= p0) continue;
-        int n_splits = 0;
+        SlabMap map{};
         rc = attend_impl(c, c->ws_ehat32.p + p0 * 256, c->ws_xq.p + p0 * 4, p1 - p0, tau_sem, tau_geo, bt,
-                         c->ws_stats.p + p0 * 4, nullptr, &n_splits, kept ? p0 : -1, stream);
+                         c->ws_stats.p + p0 * 4, nullptr, &map, kept ? p0 : -1, stream);
         if (rc) { (void)hipDeviceSynchronize(); give_back(); return rc; }
         // finalize per slab (the split slabs of this part are overwritten by the next part's pass 2,
         // which is behind these kernels in stream order)
@@ -1714,7 +1751,7 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
             slabs.push_back(sl);
             const int64_t n = sl.nq * 320;
             hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                               c->ws_slabs.p, n_splits, c->ws_ehat64.p + p0 * 256, p1 - p0, q0 - p0, sl.nq,
+                               c->ws_slabs.p, map, c->ws_ehat64.p + p0 * 256, p1 - p0, q0 - p0, sl.nq,
                                c->ws_out64.p + p0 * RANGE_OUT_DIM);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(sl.fin, s);
