@@ -236,7 +236,13 @@ int64_t range_kept_queries(const range_ctx* ctx);
  * how many queries took that path since the context was created (synchronises the device; it also
  * returns RANGE_ERR_HIP if a merging workgroup of an earlier call gave up waiting for the stream
  * workgroups - possible only when the grid cannot be resident as a whole - in which case that
- * call's results for its query carry index -1 / NaN). */
+ * call's results for its query carry index -1 / NaN).
+ * STREAM ORDER: the fused form's arrival counters are checked against a running base the HOST keeps
+ * and passes by value with each launch - one fused launch of a context in flight at a time, in the
+ * order the host issued them.  Calls on one context must therefore be issued on ONE stream (or on
+ * streams the caller orders) and must NOT be captured into a HIP graph (a replay would hand the kernel
+ * a stale base: workgroups would pick wrong merge slots or leave outputs unwritten).  A caller that
+ * needs either uses separate contexts, or RANGE_TOPKS_FUSED=0 (merge as a second launch: no counters). */
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);

@@ -32,6 +32,7 @@ logic can be exercised on CPU with the gloo backend and a checker engine in test
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -79,6 +80,13 @@ class ShardedRange:
         #: pass 1 per chunk with its collectives overlapped (needs engine.scan_stats_at); False: one
         #: pass 1 over all scanned queries between a blocking gather and a blocking all-reduce (A/B, tests)
         self.pass1_chunked = hasattr(engine, "scan_stats_at")
+        #: RANGE_DIST_BLOCKING=1: every collective is waited for where it is issued (no overlap with
+        #: compute, one pass 1 over all scanned queries) - the escape hatch for bisecting a hang or a
+        #: wrong result on a backend the overlapped schedule has not met (it has run over gloo and
+        #: the in-process test backend only; RCCL with more than one rank has not executed)
+        self.blocking = os.environ.get("RANGE_DIST_BLOCKING", "0") == "1"
+        if self.blocking:
+            self.pass1_chunked = False
         #: bytes this rank SENT / RECEIVED per kind of collective since ``reset_bytes()`` (payload
         #: sizes; "results" = what the batch drivers move to rank 0, range.ShardedLocationEncoder)
         self.bytes_sent = {}
@@ -169,6 +177,9 @@ class ShardedRange:
                 dst.copy_(h_dst)
             return land
         work = dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True)
+        if self.blocking:
+            work.wait()
+            return lambda: None
         return work.wait
 
     def _stats_start(self, stats: torch.Tensor, name: str):
@@ -177,16 +188,21 @@ class ShardedRange:
         Not an all-reduce: a ring or tree sums an element in an order that depends on where it sits
         in the buffer, so a query's l - and with it the result - would change in the last bit with
         the batch it travels in; the fixed-order merge keeps the sharded result independent of the
-        chunking and of the collective algorithm (8 B x W per query and chunk, one small kernel)."""
+        chunking and of the collective algorithm (16 B per scanned query to every peer, one small
+        kernel).  Counted and timed under the key "reduce" (what it replaces); the time is the
+        wait for the collective alone, not the merge kernel behind it."""
         out = self._buf("gather:" + name, (self.world * stats.shape[0], stats.shape[1]), stats.dtype,
                         torch.device("cpu") if self._staged(stats) else stats.device)
         nb = stats.numel() * stats.element_size()
         self._count("reduce", nb * (self.world - 1), nb * (self.world - 1))
         src = stats.cpu() if self._staged(stats) else stats
         work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        if self.blocking:
+            self._blocked("reduce", work.wait)
 
         def merged():
-            work.wait()
+            if not self.blocking:
+                self._blocked("reduce", work.wait)
             parts = out.to(stats.device).view(self.world, stats.shape[0], stats.shape[1])
             return self.engine.merge_stats(parts)
         return merged
@@ -204,13 +220,15 @@ class ShardedRange:
         # one direct transfer per peer; asynchronous, so that the exchange of this chunk
         # overlaps pass 2 of the next
         work = dist.all_to_all_single(recv, part, group=self.group, async_op=True)
+        if self.blocking:
+            self._blocked("exchange", work.wait)
         return work, (lambda: recv), part
 
     def _reduce_stats(self, stats_local: torch.Tensor) -> torch.Tensor:
         """Global softmax statistics from the shards' (the blocking form of the unchunked pass 1):
         every shard reports (m, l) with the SAME constant shift m (range_hip.h: range_scan_stats),
         so the sums l of disjoint row sets add - gathered and merged in rank order (``_stats_start``)."""
-        return self._blocked("reduce", self._stats_start(stats_local, "stats"))
+        return self._stats_start(stats_local, "stats")()
 
     def _gather_queries(self, lonlat: torch.Tensor):
         """Encode the own queries and gather every rank's scan operands: e32 (B,256) and xq (B,4)
@@ -292,7 +310,7 @@ class ShardedRange:
             st = eng.scan_stats_at(e32_all[first:first + n], xq_all[first:first + n], self.tau_sem, self.tau_geo,
                                    first, total, n_splits=n_splits)
             merged = self._stats_start(st, f"stats{len(getters)}")
-            getters.append(lambda merged=merged: self._blocked("reduce", merged))
+            getters.append(merged)
         return e64, e32_all, xq_all, chunks, getters, eng.kept_queries() == total
 
     @torch.no_grad()

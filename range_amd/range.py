@@ -98,7 +98,7 @@ class LocationEncoder(nn.Module):
     chunk_size = 16384
     #: topk(): batches up to this size go through the HBM-streaming kernel in one call (bf16-key
     #: prefilter + float32 re-rank; one launch up to 256 queries: ~20 us for 16 queries on
-    #: range_db_large, ~41 us for 64 (BENCH_r03.json roofline_scan) - faster than pass 1 + a selection
+    #: range_db_large, ~41 us for 64 (BENCH_r04.json roofline_scan) - faster than pass 1 + a selection
     #: over its kept logits at every size, tools/topk_total_time.py); larger batches in chunks of this size
     topk_stream_max = 16384
 
@@ -380,9 +380,15 @@ class ShardedLocationEncoder(nn.Module):
         return full.to(self.engine.device) if return_device else self._to_host(full)
 
     def _to_host(self, t: torch.Tensor) -> np.ndarray:
-        """``.cpu()`` synchronises: a persistent launch of this rank that gave up is known now."""
+        """``.cpu()`` synchronises: a persistent launch of this rank that gave up is known now.  The
+        rows of ANOTHER rank that did (NaN, range_hip.h: range_check_async_error) arrive with the
+        gathered result: every rank holds the same rows, so every rank refuses them here - the
+        verdict is the same on all ranks without a collective of its own."""
         h = t.cpu().numpy()
         self.engine.check_async_error()
+        if h.ndim >= 2 and h.shape[-1] == 1280 and h.size and (np.isnan(h[..., 0]).any() or np.isnan(h[..., 1024]).any()):
+            raise RuntimeError("sharded forward: rows of the result are NaN: a rank's persistent launch gave up "
+                               "(that rank reports it on its side and runs separate launches from now on): re-issue the call")
         return h
 
     @torch.no_grad()

@@ -131,7 +131,9 @@ class ShardedEmbeddingPipeline:
         self.depth = max(2, int(depth))
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._slots = [None] * self.depth       # (send rows, gathered rows on rank 0, pinned copy on rank 0)
-        self._copied = [torch.cuda.Event() for _ in range(self.depth)]
+        with torch.cuda.device(self.device):
+            self._copied = [torch.cuda.Event() for _ in range(self.depth)]
+            self._done = [torch.cuda.Event() for _ in range(self.depth)]
 
     def _buffers(self, slot: int, per: int):
         cur = self._slots[slot]
@@ -176,17 +178,20 @@ class ShardedEmbeddingPipeline:
                 dist.gather(h, parts, dst=self.root_global, group=self.group)
                 host = parts
             else:
-                done = torch.cuda.Event()
-                done.record()
-                with torch.cuda.stream(self.copy_stream):
+                # (recorded on the stream the engine launches on - torch's current stream of the ENGINE's
+                # device, whatever device is current in this thread)
+                done = self._done[slot]
+                done.record(torch.cuda.current_stream(self.device))
+                side = self.copy_stream if not sharded.blocking else torch.cuda.current_stream(self.device)
+                with torch.cuda.stream(side):
                     # the gather and the device->host copy behind it wait for THIS batch only; the
                     # compute stream goes on with the next batch
-                    self.copy_stream.wait_event(done)
+                    side.wait_event(done)
                     parts = list(gathered.view(W, per, 1280).unbind(0)) if r == 0 else None
                     dist.gather(send, parts, dst=self.root_global, group=self.group)
                     if r == 0:
                         pinned.copy_(gathered, non_blocking=True)
-                    self._copied[slot].record(self.copy_stream)
+                    self._copied[slot].record(side)
             inflight.append((slot, n, per, host))
             i += 1
         while inflight:
@@ -206,6 +211,15 @@ class ShardedEmbeddingPipeline:
             lo, hi = (n * r) // W, (n * (r + 1)) // W
             src = host[r][:hi - lo].numpy() if host is not None else self._slots[slot][2][r * per:r * per + hi - lo].numpy()
             out[lo:hi] = src
+        # The check above is this rank's own.  Another rank whose persistent launch gave up raises on
+        # ITS side and leaves NaN rows in what it sent: rank 0 - the only rank that hands rows out or
+        # writes them - refuses the batch instead of passing them on (a NaN row is NaN in every
+        # element: one column of each half is enough to look at)
+        if np.isnan(out[:, 0]).any() or np.isnan(out[:, 1024]).any():
+            bad = np.flatnonzero(np.isnan(out[:, 0]) | np.isnan(out[:, 1024]))
+            raise RuntimeError(f"sharded save_embeddings: {bad.size} of the {n} gathered rows are NaN (first: row {int(bad[0])}): "
+                               "a rank's persistent launch gave up (range_hip.h: range_check_async_error); that rank "
+                               "reports it on its side and has switched to separate launches - re-run the batch")
         return out
 
 

@@ -142,6 +142,7 @@ def _free_port():
 
 def _worker(rank, world, port, N, B, L, H, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)          # (up to 8 rank processes on this box's 8 cores)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         locs, vals, keys = synth.make_bank(N, 11)
@@ -204,8 +205,10 @@ def _worker(rank, world, port, N, B, L, H, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_forward_gloo(world):
+    """(world 8 = the north-star world size: 75-row shards, 7-peer exchanges, chunked == unchunked,
+    byte counters - as eight gloo rank processes)"""
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), 601, 200, 10, 64, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
@@ -356,3 +359,84 @@ def test_embed_refuses_a_b_max_below_the_own_count():
             model.embed(torch.zeros((5, 2), dtype=torch.float64), b_max=4)
     finally:
         dist.destroy_process_group()
+
+
+# ---- world 8 beyond the plain forward: ragged and empty shares, every row_shards divisor (8x1, 4x2,
+#      2x4, 1x8), the blocking escape hatch - eight rank THREADS of this process on torch's in-process
+#      backend (tests/_thread_ranks.py: the world size of the north star, at the price of one process)
+from _thread_ranks import run_rank_threads, threaded_backend_available  # noqa: E402
+
+needs_threads = pytest.mark.skipif(not threaded_backend_available(), reason="torch's threaded process group is not in this build")
+
+
+def _w8_setup(rank, R=None, group=None):
+    N, L, H = 601, 10, 64
+    locs, vals, keys = synth.make_bank(N, 11)
+    full = O.prep_bank(locs, vals, keys)
+    world = dist.get_world_size(group)
+    R = R or world
+    si = dist.get_rank(group) % R
+    r0, r1 = shard_rows(N, R, si)
+    w = synth.make_encoder_weights(L, H, 256, 2, 5)
+    return full, O.Bank(full.keys[r0:r1], full.values[r0:r1], full.xyz[r0:r1]), r0, w, L
+
+
+def _w8_ragged(rank, world):
+    full, shard, r0, w, L = _w8_setup(rank)
+    model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5)
+    model.min_chunk = 2
+    # 1 250-query-like ragged shares scaled down: some ranks bring nothing, one brings far more
+    for counts, chunk in (((5, 0, 130, 64, 0, 1, 77, 12), 64), ((0, 0, 0, 0, 0, 0, 0, 9), None), ((66,) * 8, 32)):
+        B = counts[rank]
+        q = synth.make_queries(max(B, 1), seed=300 + rank)[:B]
+        out = model.embed(torch.from_numpy(q), chunk=chunk).numpy()
+        assert out.shape == (B, 1280)
+        if B:
+            assert float(np.abs(out - O.forward(q, w, L, full, "RANGE+", 0.5)).max()) < 1e-5, counts
+        tv, ti = model.embed_topk(torch.from_numpy(q), 8, chunk=chunk)
+        assert tuple(ti.shape) == (B, 8)
+        if B:
+            s, _ = O.logits64(O.encode(q, w, L), q, full)
+            assert np.array_equal(ti.numpy(), O.topk64(s, 8)[1])
+    # equal shares: the byte counters of one forward at world 8 (7 peers)
+    B = 128
+    q = synth.make_queries(B, seed=40 + rank)
+    model.reset_bytes()
+    out = model(torch.from_numpy(q)).numpy()
+    assert float(np.abs(out - O.forward(q, w, L, full, "RANGE+", 0.5)).max()) < 1e-5
+    assert model.bytes_sent["gather"] == B * 1040 * 7 and model.bytes_sent["reduce"] == 8 * B * 16 * 7
+    assert model.bytes_sent["exchange"] == B * 4096 * 7 == model.bytes_received["exchange"]
+    # the blocking escape hatch gives the same bits
+    blocking = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5)
+    blocking.min_chunk = 2
+    blocking.blocking, blocking.pass1_chunked = True, False
+    assert np.array_equal(blocking(torch.from_numpy(q)).numpy(), out)
+
+
+def _w8_layout(rank, world, R):
+    from range_amd.dist import make_layout
+    group, si, qg = make_layout(R)
+    assert (si, qg) == (rank % R, rank // R)
+    full, shard, r0, w, L = _w8_setup(rank, R)
+    model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5, group=group)
+    assert model.world == R and model.rank == si
+    B = 70 + rank
+    q = synth.make_queries(B, seed=400 + rank)
+    out = model.embed(torch.from_numpy(q), chunk=64).numpy()
+    assert out.shape == (B, 1280) and float(np.abs(out - O.forward(q, w, L, full, "RANGE+", 0.5)).max()) < 1e-5
+    sw = model.embed_sweep(torch.from_numpy(q), (0.0, 1.0)).numpy()
+    for j, b in enumerate((0.0, 1.0)):
+        assert float(np.abs(sw[j] - O.forward(q, w, L, full, "RANGE+", b)).max()) < 1e-5
+
+
+@needs_threads
+def test_world8_ragged_and_empty_shares_rank_threads():
+    res = run_rank_threads(8, _w8_ragged)
+    assert res == {r: "ok" for r in range(8)}, res
+
+
+@needs_threads
+@pytest.mark.parametrize("R", [1, 2, 4, 8])
+def test_world8_every_layout_rank_threads(R):
+    res = run_rank_threads(8, _w8_layout, R)
+    assert res == {r: "ok" for r in range(8)}, res

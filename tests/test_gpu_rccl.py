@@ -64,10 +64,6 @@ def _sample_check(out_rows, q_rows, obank, w, betas):
 
 def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
     import torch.distributed as dist
-    from oracle import range_oracle as O
-    from range_amd import load_model
-    from range_amd.save import save_embeddings
-    from tools import synth
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
         dev = torch.device("cuda", rank)
@@ -77,6 +73,24 @@ def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
         dev = torch.device("cuda", 0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _body(rank, world, dev, ck, rbank, tmp, backend)
+        ret[rank] = "ok"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
+    finally:
+        dist.destroy_process_group()
+
+
+def _body(rank, world, dev, ck, rbank, tmp, backend, total_queries=100_000):
+    """What every rank does, whatever carries the collectives (RCCL; gloo ranks sharing a GPU; the rank
+    THREADS of tests/test_gpu_world8.py).  ``total_queries``: the C4 batch over all ranks."""
+    import torch.distributed as dist
+    from oracle import range_oracle as O
+    from range_amd import load_model
+    from range_amd.save import save_embeddings
+    from tools import synth
+    if True:
         assert dist.get_backend() == backend
         obank = O.prep_bank(*_bank_arrays())
         w = synth.make_encoder_weights(L, H, 256, 2, SEED)
@@ -84,7 +98,7 @@ def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
         m = load_model("RANGE+", pretrained_path=ck, device=dev, db_path=rbank, beta=0.5, shards=world)
         assert m.row_range == ((N * rank) // world, (N * (rank + 1)) // world)
         # ---- C4 shape: 100 000 queries over the ranks, ragged, pole to pole
-        B = 100_000 // world + rank
+        B = total_queries // world + rank
         q = synth.make_queries(B, seed=70 + rank, lat_max=90.0)
         x = torch.from_numpy(q).to(dev)
         m.sharded.comm_timing(True)
@@ -150,12 +164,6 @@ def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
         z = np.load(os.path.join(tmp, "emb", "RANGE+", "t_train.npz"))
         assert z["embeddings"].shape == (1463, 1280)
         _sample_check(z["embeddings"][None, :32], z["coords"][:32], obank, w, (0.5,))
-        ret[rank] = "ok"
-    except Exception as ex:  # noqa: BLE001
-        import traceback
-        ret[rank] = f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}"
-    finally:
-        dist.destroy_process_group()
 
 
 def test_rccl_row_sharded_at_c4_c5_shapes(tmp_path):
