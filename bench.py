@@ -241,11 +241,37 @@ def pmc_traffic(kernel, B, N, qt, ns):
     return None, "no PMC entry for this workload/geometry in profiles/attend_pmc.json", None
 
 
+#: untimed activity in front of the warm-up steps of every timed leg.  The chip lowers its clock when
+#: idle and takes ~35 ms of continuous work to raise it again (tools/clock_ramp.py, round 5: the first
+#: launches of a 2 ms kernel after a pause run up to 25 % slower, and with 3 ms of idle time between
+#: launches the clock never recovers).  A rank's step of an 8-GPU run takes ~3 ms, so W = 3 warm-up steps
+#: end inside that ramp; the steady state - what a job embedding millions of locations sees - is what
+#: the metric is about.  The W warm-up steps and the K timed steps follow unchanged.
+PREHEAT_MS = 150.0
+
+
 def main():
     a = parse()
+    backend = os.environ.get("RANGE_DIST_BACKEND", "nccl")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if backend == "threads":
+            # rehearsal of the N-rank code path inside ONE process: the ranks are threads sharing cuda:0
+            # (tools/thread_ranks.py; a box of this pool admits 6 processes on its card, the north star
+            # has 8 ranks).  Every leg of the N-rank bench runs; the timing means nothing.
+            import torch
+            from tools.thread_ranks import run_rank_threads
+            torch.cuda.init()             # (once, in front of the threads)
+            res = run_rank_threads(a.gpus, lambda rank, world: rank_main(a, rank, 0, world, "threads"), timeout=3000.0)
+            bad = {r: v for r, v in res.items() if v != "ok"}
+            if bad:
+                print(bad, file=sys.stderr)
+            sys.exit(1 if bad else 0)
         sys.exit(spawn_ranks(a))
+    rank_main(a, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+              int(os.environ.get("WORLD_SIZE", "1")), backend)
 
+
+def rank_main(a, rank, local, world, backend):
     import numpy as np
     import torch
 
@@ -253,21 +279,17 @@ def main():
     from tools import synth
     from range_amd.bank import prepare_bank
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    # RANGE_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
-    # (ranks share devices, collectives are staged through the host; the timing means nothing)
-    backend = os.environ.get("RANGE_DIST_BACKEND", "nccl")
+    # RANGE_DIST_BACKEND=gloo / threads: rehearsal of the N>1 code path on a box with fewer GPUs than
+    # ranks (ranks share devices; gloo stages the collectives through the host; the timing means nothing)
     n_dev = torch.cuda.device_count()
     if backend == "nccl" and world > n_dev:
         raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, {n_dev} visible "
-                         "(RANGE_DIST_BACKEND=gloo rehearses the path on fewer)")
-    dev = torch.device("cuda", local if backend == "nccl" else local % n_dev)
+                         "(RANGE_DIST_BACKEND=gloo or =threads rehearses the path on fewer)")
+    dev = torch.device("cuda", local if backend == "nccl" else local % max(1, n_dev))
     torch.cuda.set_device(dev)
     dist = None
     import re as _re
@@ -287,7 +309,8 @@ def main():
     if world > 1 or sharded:
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, make_layout, shard_rows
-        init_from_env(backend)
+        if backend != "threads":          # (the rank threads arrive inside an initialised group)
+            init_from_env(backend)
 
     L, H = 40, a.hidden
     N = synth.BANK_ROWS[a.bank]
@@ -360,6 +383,20 @@ def main():
             else:
                 model.embed_sweep(x, betas, out=out, b_max=B)
 
+        # untimed pre-heat (PREHEAT_MS): the same step until the chip has been busy long enough to hold
+        # its clock; every rank runs the same count (the slowest rank's first step sets it)
+        fence()
+        t0 = time.perf_counter()
+        step()
+        fence()
+        t_first = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([t_first], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_first = float(t.item())
+        n_pre = min(200, int(PREHEAT_MS * 1e-3 / max(t_first, 1e-4)))
+        for _ in range(n_pre):
+            step()
         for _ in range(warmup):
             step()
         eng.profile_enable(True)
@@ -383,7 +420,7 @@ def main():
         assert prof["attend"][1] >= steps and prof["attend"][1] % steps == 0, (prof, steps)
         assert bool(torch.isfinite(out[..., :8]).all()) and bool(torch.isfinite(out[..., -8:]).all())
         return {"B": B, "dt": dt, "prof": prof, "comm_ms": comm_ms, "q_host": q_host, "out": out,
-                "kept": eng.kept_queries() > 0, "geometry": eng.last_geometry()}
+                "kept": eng.kept_queries() > 0, "geometry": eng.last_geometry(), "preheat_steps": n_pre + 1}
 
     def per_step(comm_ms, steps):
         """Exposed communication per step, split per kind of collective (ShardedRange.comm_timing)."""
@@ -533,6 +570,8 @@ def main():
             "value": total_q / dt,
             "unit": "geo-embeddings/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "preheat": {"untimed_steps_before_warmup": m["preheat_steps"], "target_ms": PREHEAT_MS,
+                        "why": "the chip needs ~35 ms of continuous work after idling to hold its clock (tools/clock_ramp.py)"},
             "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -602,7 +641,8 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if backend != "threads":
+            dist.destroy_process_group()
 
 
 def opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev):

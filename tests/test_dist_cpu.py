@@ -363,8 +363,8 @@ def test_embed_refuses_a_b_max_below_the_own_count():
 
 # ---- world 8 beyond the plain forward: ragged and empty shares, every row_shards divisor (8x1, 4x2,
 #      2x4, 1x8), the blocking escape hatch - eight rank THREADS of this process on torch's in-process
-#      backend (tests/_thread_ranks.py: the world size of the north star, at the price of one process)
-from _thread_ranks import run_rank_threads, threaded_backend_available  # noqa: E402
+#      backend (tools/thread_ranks.py: the world size of the north star, at the price of one process)
+from tools.thread_ranks import run_rank_threads, threaded_backend_available  # noqa: E402
 
 needs_threads = pytest.mark.skipif(not threaded_backend_available(), reason="torch's threaded process group is not in this build")
 

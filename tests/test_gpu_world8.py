@@ -3,12 +3,12 @@
 (tests/test_gpu_rccl.py::_body: C4 shape with ragged shares, chunked == unchunked pass 1, top-k with one
 all-gather, the beta sweep, every ``row_shards`` divisor of 8 - 1x8, 2x4, 4x2 beside 8x1 -, the drop-in
 call, the sharded ``save_embeddings``).  The pool's boxes admit 6 processes on a card, so the ranks are
-threads of this process (tests/_thread_ranks.py) and the collectives plain device copies; the shapes, the
+threads of this process (tools/thread_ranks.py) and the collectives plain device copies; the shapes, the
 chunk schedule, the buffers and the order of the collectives are those of an 8-GPU run."""
 import pytest
 import torch
 
-from _thread_ranks import run_rank_threads, threaded_backend_available     # (tests/ is on sys.path: pytest's prepend mode)
+from tools.thread_ranks import run_rank_threads, threaded_backend_available
 from test_gpu_rccl import H, L, SEED, _bank_arrays, _body
 
 pytestmark = pytest.mark.gpu

@@ -1,4 +1,5 @@
-"""W ranks of a torch.distributed job as W THREADS of this process (test infrastructure).
+"""W ranks of a torch.distributed job as W THREADS of this process (test / rehearsal infrastructure:
+tests/test_gpu_world8.py, tests/test_dist_cpu.py, ``RANGE_DIST_BACKEND=threads python bench.py --gpus 8``).
 
 A GPU box of this pool admits at most 6 processes on its card, and the north-star world size is 8:
 the ranks of the world-8 GPU tests are therefore threads, each with its own engine context on
