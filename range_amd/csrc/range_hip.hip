@@ -19,6 +19,7 @@
 #include "host_plan.h"
 #include "attend_kernels.h"
 #include "topk_stream.h"
+#include "topk_gemm.h"
 #include "attend_bf16x3.h"
 #include "attend_small.h"
 #include "encoder_kernel.h"
@@ -93,6 +94,11 @@ struct range_ctx {
     uint32_t topk_sync_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the counters read when the next fused launch starts
     bool debug_giveup_next = false;          // range_debug_raise_async_error: the next persistent launch gives up
     bool has_values = false;                 // false: keys-only bank (range_set_keys): top-k side channel only
+    int tg_sample = TG_SAMPLE;               // RANGE_TG_SAMPLE=n: pass A of the batch top-k looks at every n-th tile (tuning)
+    bool topk_gemm = true;                   // RANGE_TOPK_GEMM=0: batches beyond 256 queries through the streaming scan too (A/B)
+    DevBuf<float> ws_tg_gmax, ws_tg_theta;   // topk_gemm.h: group maxima (n_splits * 2, B, 4), thresholds (B)
+    DevBuf<uint32_t> ws_tg_cnt, ws_tg_ovf;
+    DevBuf<uint2> ws_tg_cand;                  // candidate lists: lengths (B, lists), rows (B, lists, TG_CAP_L); overflow flags (B)
     int p2_splits_forced = 0;                // RANGE_P2_SPLITS=n: pass 2 with n bank splits (tuning)
     bool small_forward = true;               // RANGE_SMALL_FORWARD=0: batches of <= 32 queries take the two-pass kernels too (A/B)
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
@@ -521,6 +527,8 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_TOPKS_KEYS")) c->topks_bf16 = std::strcmp(e, "f32") != 0;
     if (const char* e = std::getenv("RANGE_TOPKS_FUSED")) c->topks_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_SMALL_FORWARD")) c->small_forward = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_TOPK_GEMM")) c->topk_gemm = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_TG_SAMPLE")) c->tg_sample = std::max(1, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("RANGE_P2_SPLITS")) c->p2_splits_forced = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RANGE_P2_STREAMK")) c->p2_streamk = e[0] != '0';
     if (const char* e = std::getenv("RANGE_P2_COL_ROWS")) c->p2_col_rows = std::max(64, std::atoi(e));
@@ -1077,6 +1085,75 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + NWV - 1) / NWV));
     // the merge runs as the tail of the stream kernel while every query finds a workgroup of its own
     const bool fused = c->topks_fused && B <= n_wg;
+    if (c->topk_gemm && bf16 && B > 256 && n_blocks >= 64 && !c->topks_force_exact) {
+        // batches beyond the one-launch regime: GEMM-shaped, list-free (topk_gemm.h): group maxima ->
+        // per-query threshold -> candidates -> float32 re-rank.  Two workgroups per CU; the splits fill
+        // one round of them (at least 4: 32 row groups for the threshold; at least 8 tiles each).
+        TopkGemmArgs ga{};
+        ga.keys_bf16 = c->d_keys_bf16.p;
+        ga.keys = c->d_keys.p;
+        ga.ehat = ehat32;
+        ga.B = B;
+        ga.n_valid = c->n_rows;
+        ga.n_blocks = n_blocks;
+        ga.n_qblocks = (int32_t)((B + TG_QBLOCK - 1) / TG_QBLOCK);
+        ga.n_splits = std::max(4, std::min(std::min(2 * c->n_cu / ga.n_qblocks, n_blocks / 8), 64));
+        ga.k = k;
+        ga.row_offset = c->row_offset;
+        ga.oval = topk_val;
+        ga.oidx = topk_idx;
+        if (!c->ws_exact_count.p) {
+            HIP_TRY(c->ws_exact_count.ensure(2));
+            HIP_TRY(hipMemsetAsync(c->ws_exact_count.p, 0, 2 * sizeof(int32_t), s));
+        }
+        ga.exact_count = c->ws_exact_count.p;
+        HIP_TRY(c->ws_tg_gmax.ensure((size_t)ga.n_splits * 2 * B * 4));
+        HIP_TRY(c->ws_tg_theta.ensure((size_t)B * 2));
+        HIP_TRY(c->ws_tg_cnt.ensure((size_t)B * ga.n_splits * 4));
+        HIP_TRY(c->ws_tg_cand.ensure((size_t)B * ga.n_splits * 4 * TG_CAP_L));
+        HIP_TRY(c->ws_tg_ovf.ensure((size_t)B));
+        ga.ovf = c->ws_tg_ovf.p;
+        ga.gmax = c->ws_tg_gmax.p;
+        ga.theta = c->ws_tg_theta.p;
+        ga.cnt = c->ws_tg_cnt.p;
+        ga.cand = c->ws_tg_cand.p;
+        int rcg = set_dyn_lds(topk_gemm_kernel<0>, TG_LDS_BYTES);
+        if (rcg) return rcg;
+        rcg = set_dyn_lds(topk_gemm_kernel<1>, TG_LDS_BYTES);
+        if (rcg) return rcg;
+        hipEvent_t g0 = nullptr, g1 = nullptr;
+        if (repeats > 1) {
+            g0 = c->get_event();
+            g1 = c->get_event();
+            HIP_TRY(hipEventRecord(g0, s));
+        }
+        const dim3 ggrid((unsigned)(ga.n_qblocks * ga.n_splits));
+        for (int rep = 0; rep < std::max(1, repeats); ++rep) {
+            {
+                ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);
+                ga.tile_stride = std::max(1, std::min(c->tg_sample, n_blocks / ga.n_splits / 4));
+                hipLaunchKernelGGL(topk_gemm_kernel<0>, ggrid, dim3(256), TG_LDS_BYTES, s, ga);
+                ga.tile_stride = 1;
+                hipLaunchKernelGGL(topk_gemm_threshold_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ga.gmax,
+                                   ga.n_splits * 2, B, ehat32, TG_EPS_REL * c->key_norm_max, c->ws_tg_theta.p);
+                hipLaunchKernelGGL(topk_gemm_kernel<1>, ggrid, dim3(256), TG_LDS_BYTES, s, ga);
+            }
+            ProfScope ps(c, RANGE_PROF_TOPK_MERGE, s);
+            hipLaunchKernelGGL(topk_gemm_rerank_kernel, dim3((unsigned)B), dim3(256), 0, s, ga);
+            hipLaunchKernelGGL(topk_gemm_brute_kernel, dim3((unsigned)std::min<int64_t>(B, 2 * c->n_cu)), dim3(256), 0, s, ga);
+            HIP_TRY(hipGetLastError());
+        }
+        if (repeats > 1) {
+            HIP_TRY(hipEventRecord(g1, s));
+            HIP_TRY(hipEventSynchronize(g1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, g0, g1));
+            if (avg_us) *avg_us = ms * 1e3f / (float)repeats;
+            c->ev_pool.push_back(g0);
+            c->ev_pool.push_back(g1);
+        }
+        return RANGE_OK;
+    }
     HIP_TRY(c->ws_cand_keys.ensure((size_t)n_groups * 16 * n_wg * TOPKS_WL));
     HIP_TRY(c->ws_cand_dmax.ensure((size_t)n_groups * 16 * n_wg));
     if (!c->ws_exact_count.p) {

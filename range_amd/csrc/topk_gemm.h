@@ -1,0 +1,373 @@
+// Batch-scale top-k (range_topk_stream for batches beyond the one-launch regime: B > 256).
+//
+// The streaming scan of topk_stream.h is built for a handful of queries: 16 or 32 of them per pass
+// over the keys, every value pushed through per-lane candidate lists.  At BASELINE's batch (10 000
+// queries against range_db_large) that is 313 passes re-streaming a bank that sits in the Infinity
+// Cache, bound by list maintenance and pass seams (3.9 ms, round 4) - while the arithmetic,
+// 2 x 256 x 10^9 FLOP, is 0.2 ms of bf16 MFMA.  Here the scan is GEMM-shaped and list-free:
+//
+//   pass A  topk_gemm_kernel<0>  approximate similarities S~ = K~ Q~^T (bf16 operands, f32
+//           accumulation: v_mfma_f32_16x16x32_bf16) of a SAMPLE of the bank - every TG_SAMPLE-th
+//           16-row tile - of which only the MAXIMUM per (query, row group) is kept: one v_max per
+//           value.  Row groups = bank splits x 2 tile parities x 4 accumulator lane groups:
+//           disjoint row sets, at least 16 of them.
+//   theta   per query the 16th largest group maximum: at least 16 rows have S~ >= theta~ (a lower
+//           bound from the sample: looser than the whole bank's by about log2(TG_SAMPLE) ranks'
+//           worth of rows, at 1 / TG_SAMPLE of a pass)
+//   pass B  topk_gemm_kernel<1>  the products of ALL rows; every row with S~ >= theta~ - 2 eps is
+//           appended, with its S~, to a candidate list (one compare per tile and lane; the append is
+//           a rare branch).  A lane owns the list of its (query, bank split, accumulator lane group)
+//           outright - TG_CAP_L slots and a counter in a register - so an append is one plain
+//           store: no atomic, no wait (with one list per query filled through returning atomics
+//           the waves spent 54 % of their cycles waiting)
+//   rerank  topk_gemm_rerank_kernel: v16 = the 16th largest S~ of the query's candidates (the 16
+//           largest S~ of the whole bank are among them); the candidates with S~ >= v16 - 2 eps get
+//           their FLOAT32 similarity by the fmaf chain every float32 kernel of this library computes
+//           (topk_exact_dot) and are ranked by (value, lower row first): values and indices are
+//           those of the float32 scan, bit for bit.
+//
+// Exactness: |S~ - S| <= eps = TG_EPS_REL |q| max|k| for every pair.  At least 16 rows have
+// S~ >= v16, hence S >= v16 - eps: the 16th best exact value is >= v16 - eps and every member of the
+// exact top 16 has S~ >= v16 - 2 eps (>= theta~ - 2 eps: it was appended).  A query whose lists
+// overflow (a bank of near-duplicates; a sample that missed the query's neighbourhood) is recomputed
+// by brute force (topk_gemm_brute_kernel): slower, never wrong.
+//
+// Decomposition: workgroup = 4 waves = 256 queries (wave w: 4 groups of 16 queries, their bf16
+// fragments in 128 registers for the whole kernel) x one bank split; key tiles (16 rows = 8 KB in
+// the fragment order keyfrag_kernel wrote) arrive by LDS-DMA in phases of 2 tiles through a 3-slot
+// ring shared by the 4 waves, one barrier per phase; per tile and wave 4 x 8 MFMAs.  Two
+// workgroups per CU (48 KB of LDS, <= 256 registers): one's MFMAs cover the other's barrier.
+#pragma once
+#include "topk_stream.h"
+
+namespace range_hip {
+
+constexpr int TG_GQ = 4;                     // query groups (of 16) per wave
+constexpr int TG_QBLOCK = 4 * TG_GQ * 16;    // queries per workgroup
+constexpr int TG_KT = 2;                     // key tiles per phase
+constexpr int TG_SLOTS = 3;
+constexpr int TG_LDS_BYTES = TG_SLOTS * TG_KT * TSB_TILE_BYTES;   // 48 KB
+constexpr int TG_SAMPLE = 4;                 // pass A looks at every 4th tile
+constexpr int TG_CAP = 1024;                 // candidates of a query the re-rank takes in (all lists together)
+constexpr int TG_CAP_L = 32;                 // slots per (query, bank split, lane group) list
+constexpr int TG_CAP_X = 256;                // candidates whose float32 similarity the re-rank evaluates
+// eps / (|q| |k|): key rounding 2^-9 + query rounding 2^-9 + their product 2^-18 = 0.0039101, bf16
+// MFMA accumulation (256 terms, f32) 1.6e-5, the float32 chain's own rounding 1.5e-5: 0.0039411
+constexpr float TG_EPS_REL = 0.0040f;
+
+struct TopkGemmArgs {
+    const void* keys_bf16;      // (n_tiles, 8 chunks, 64 lanes, 8) bf16 (keyfrag_kernel)
+    const float* keys;          // (n_pad, 256) f32 (rerank)
+    const float* ehat;          // (B, 256)
+    int64_t B;
+    int64_t n_valid;
+    int32_t n_blocks;
+    int32_t n_qblocks;          // ceil(B / TG_QBLOCK)
+    int32_t n_splits;
+    float* gmax;                // pass A out: (n_splits * 2, B, 4) group maxima of the approximate similarity
+    const float* theta;         // pass B in: (B, 2) candidate threshold on the approximate value (2 eps below theta~), 2 eps
+    uint32_t* cnt;              // (B, n_splits * 4) candidates each list was offered (may exceed TG_CAP_L: overflow)
+    uint2* cand;                // (B, n_splits * 4, TG_CAP_L) candidates: (row, bits of S~)
+    int32_t tile_stride;        // pass A: TG_SAMPLE (a sample of the tiles); pass B: 1
+    uint32_t* ovf;              // (B) rerank -> brute force: 1 = a list or the query's total overflowed
+    int32_t k;
+    int64_t row_offset;
+    float* oval;                // (B, k)
+    int64_t* oidx;              // (B, k)
+    int32_t* exact_count;       // queries recomputed by brute force (optional)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    // consecutive workgroups take the query blocks of ONE split: its key tiles are shared in L2
+    const int split = (int)blockIdx.x / a.n_qblocks, qb = (int)blockIdx.x - split * a.n_qblocks;
+    // the split's tiles, or (pass A) every tile_stride-th of them: "tile" counts the visited ones
+    const int t0 = (int)(((int64_t)split * a.n_blocks) / a.n_splits);
+    const int t1 = (int)(((int64_t)(split + 1) * a.n_blocks) / a.n_splits);
+    const int stride = a.tile_stride;
+    const int b0 = 0, b1 = (t1 - t0 + stride - 1) / stride;
+    const int n_phase = (b1 - b0 + TG_KT - 1) / TG_KT;
+    const int64_t q0 = (int64_t)qb * TG_QBLOCK + wave * (TG_GQ * 16);
+
+    // B operand: lane (n = query j, kg = g) holds Q[j][32 c + 8 g + 0..7] of chunk c, one bf16 plane
+    ts_u32x4 qf[TG_GQ][8];
+#pragma unroll
+    for (int gi = 0; gi < TG_GQ; ++gi) {
+        const int64_t q = q0 + gi * 16 + j;
+        const f32x4* rowp = reinterpret_cast<const f32x4*>(a.ehat + (q < a.B ? q : a.B - 1) * KEY_DIM);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v0 = rowp[8 * c + 2 * g], v1 = rowp[8 * c + 2 * g + 1];
+            qf[gi][c][0] = ts_cvt_pk_bf16(v0.x, v0.y);
+            qf[gi][c][1] = ts_cvt_pk_bf16(v0.z, v0.w);
+            qf[gi][c][2] = ts_cvt_pk_bf16(v1.x, v1.y);
+            qf[gi][c][3] = ts_cvt_pk_bf16(v1.z, v1.w);
+        }
+    }
+    float th[TG_GQ];            // pass B: this lane's query's threshold per group
+    float mx[TG_GQ][2];         // pass A: running maxima per group and tile parity
+    uint32_t nc[TG_GQ];         // pass B: candidates this lane's list of the group's query was offered
+    bool qok[TG_GQ];
+#pragma unroll
+    for (int gi = 0; gi < TG_GQ; ++gi) {
+        const int64_t q = q0 + gi * 16 + j;
+        qok[gi] = q < a.B;
+        th[gi] = MODE == 1 ? a.theta[2 * (q < a.B ? q : a.B - 1)] : 0.f;
+        mx[gi][0] = mx[gi][1] = -INFINITY;
+        nc[gi] = 0u;
+    }
+    // (ordinary loads: hipcc's waits for them end here, in front of the hand-counted ring)
+#pragma unroll
+    for (int gi = 0; gi < TG_GQ; ++gi) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(qf[gi][c]));
+        asm volatile("" : "+v"(th[gi]));
+    }
+
+    // ring: phase p = tiles b0 + TG_KT p .. ; wave w moves half (w & 1) of tile (w >> 1): 4 x 1 KB
+    const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
+    const char* kb = reinterpret_cast<const char*>(a.keys_bf16);
+    const int last = b1 - 1;
+    auto issue = [&](int p) __attribute__((always_inline)) {
+        const int tile = min(b0 + p * TG_KT + (wave >> 1), last);      // (past the split's end: re-read its last tile)
+        const char* src = kb + ((int64_t)t0 + (int64_t)tile * stride) * TSB_TILE_BYTES + (wave & 1) * 4096;
+        const uint32_t dst = lds0 + ((p % TG_SLOTS) * TG_KT + (wave >> 1)) * TSB_TILE_BYTES + (wave & 1) * 4096;
+        dma_group_begin(dst);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) dma_b128_q(src, (uint32_t)(lane << 4), i4);
+    };
+    issue(0);
+    issue(1);
+
+    uint32_t prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
+    const uint32_t n_valid32 = (uint32_t)a.n_valid;
+
+    // what a tile's 4 x 4 approximate values per lane are used for
+    auto consume = [&](const f32x4 (&acc)[TG_GQ], int tile) __attribute__((always_inline)) {
+        const uint32_t row0 = (uint32_t)(t0 + tile * stride) * BLK;
+        const bool full = row0 + BLK <= n_valid32;          // (only the bank's last tile can hold pad rows)
+#pragma unroll
+        for (int gi = 0; gi < TG_GQ; ++gi) {
+            f32x4 s = acc[gi];
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] = row0 + prow[r] < n_valid32 ? s[r] : -INFINITY;
+            }
+            const float m4 = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            if (MODE == 0) {
+                if (tile & 1) mx[gi][1] = fmaxf(mx[gi][1], m4);
+                else mx[gi][0] = fmaxf(mx[gi][0], m4);
+            } else if (m4 >= th[gi] && qok[gi]) {
+                uint2* list = a.cand + (((q0 + gi * 16 + j) * a.n_splits + split) * 4 + g) * TG_CAP_L;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s[r] >= th[gi]) {
+                        if (nc[gi] < (uint32_t)TG_CAP_L) list[nc[gi]] = make_uint2(row0 + prow[r], __float_as_uint(s[r]));
+                        ++nc[gi];
+                    }
+                }
+            }
+        }
+    };
+
+    f32x4 prev[TG_GQ];
+    int prev_tile = -1;
+    for (int p = 0; p < n_phase; ++p) {
+        // phase p has landed when at most the 4 operations of phase p + 1 are outstanding (own share;
+        // the barrier makes it everybody's); every wave is then also done reading phase p - 1, whose
+        // slot phase p + 2 takes
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        issue(p + 2);
+        const char* slot = smem + (p % TG_SLOTS) * TG_KT * TSB_TILE_BYTES + lane * 16;
+#pragma unroll
+        for (int t = 0; t < TG_KT; ++t) {
+            const int tile = b0 + p * TG_KT + t;
+            if (tile >= b1) break;
+            ts_u32x4 kf[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const ts_u32x4*>(slot + t * TSB_TILE_BYTES + c * 1024);
+            f32x4 acc[TG_GQ];
+#pragma unroll
+            for (int gi = 0; gi < TG_GQ; ++gi) {
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ts_bf16x8, kf[c]),
+                                                                 __builtin_bit_cast(ts_bf16x8, qf[gi][c]), c0, 0, 0, 0);
+                acc[gi] = c0;
+            }
+            // the previous tile's values, in the shadow of this tile's chains
+            if (prev_tile >= 0) consume(prev, prev_tile);
+#pragma unroll
+            for (int gi = 0; gi < TG_GQ; ++gi) prev[gi] = acc[gi];
+            prev_tile = tile;
+        }
+    }
+    if (prev_tile >= 0) consume(prev, prev_tile);
+    // the clamped prefetches of the last phases are still in flight into this workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int gi = 0; gi < TG_GQ; ++gi) {
+        const int64_t q = q0 + gi * 16 + j;
+        if (q < a.B) {
+            if (MODE == 0) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par)
+                    a.gmax[((int64_t)(split * 2 + par) * a.B + q) * 4 + g] = mx[gi][par];
+            } else {
+                a.cnt[(q * a.n_splits + split) * 4 + g] = nc[gi];
+            }
+        }
+    }
+}
+
+// theta[q] = {(the 16th largest of the query's n_parts x 4 group maxima) - 2 eps, 2 eps}, eps = eps_kmax |q|
+// (with 1e-4 of slack for the rounding of the norm and of the subtraction);
+// -inf when fewer than 16 groups saw a row (every row is then a candidate).  One wave per query.
+__global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* __restrict__ gmax, int n_parts, int64_t B,
+                                                                  const float* __restrict__ ehat, float eps_kmax,
+                                                                  float* __restrict__ theta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= B) return;
+    KeyList L;
+    L.init();
+    const int total = n_parts * 4;
+    for (int e = lane; e < total; e += 64) {
+        const float v = gmax[((int64_t)(e >> 2) * B + q) * 4 + (e & 3)];
+        if (v > -INFINITY) L.push(topk_key(v, (uint32_t)e));
+    }
+    merge_wave(L);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ehat + q * KEY_DIM + 4 * lane);
+    float sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) {
+        const float t16 = L.k[MAX_TOPK - 1] ? topk_key_val(L.k[MAX_TOPK - 1]) : -INFINITY;
+        // (the margin carries 1e-4 of slack: the rounding of this subtraction and of the norm)
+        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f;
+        theta[2 * q] = t16 > -INFINITY ? t16 - eps2 : -INFINITY;
+        theta[2 * q + 1] = eps2;
+    }
+}
+
+// The candidates of one query -> its top k: one workgroup per query.
+//   1. the lists' lengths (n_splits x 4 of them), a prefix sum, the entries compacted into LDS as
+//      64-bit keys (ordered bits of S~, ~row);
+//   2. v16 = the 16th largest S~ (rank by counting);
+//   3. the entries with S~ >= v16 - 2 eps (at most TG_CAP_X): float32 similarity by the fmaf chain
+//      (one thread per entry), ranked by counting; ranks 0..k-1 are the result.
+// A query with a list that overflowed, more than TG_CAP candidates or more than TG_CAP_X in step 3 is
+// handed to topk_gemm_brute_kernel.
+constexpr int TG_RR_LDS = KEY_DIM * 4 + TG_CAP * 8 + 256 * 4 + TG_CAP_X * 8 + 32;
+__global__ __launch_bounds__(256, 4) void topk_gemm_rerank_kernel(TopkGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[TG_RR_LDS];
+    float* sh_q = reinterpret_cast<float*>(lds);
+    unsigned long long* ka = reinterpret_cast<unsigned long long*>(lds + KEY_DIM * 4);     // [TG_CAP] approximate keys
+    uint32_t* sh_c = reinterpret_cast<uint32_t*>(ka + TG_CAP);                            // [256] list lengths
+    unsigned long long* kx = reinterpret_cast<unsigned long long*>(sh_c + 256);           // [TG_CAP_X] exact keys
+    int* sh_i = reinterpret_cast<int*>(kx + TG_CAP_X);          // [0] overflow, [1] entries of step 3, [2..3] v16 key
+    const int64_t q = blockIdx.x;
+    const int t = threadIdx.x;
+    const int R = a.n_splits * 4;                                    // lists of this query (<= 256)
+    const uint32_t c = t < R ? a.cnt[q * R + t] : 0u;
+    sh_c[t] = c;
+    sh_q[t] = a.ehat[q * KEY_DIM + t];
+    if (t < 4) sh_i[t] = 0;
+    __syncthreads();
+    if (c > (uint32_t)TG_CAP_L) sh_i[0] = 1;
+    uint32_t off = 0, total = 0;
+    for (int u = 0; u < R; ++u) {
+        const uint32_t cu = sh_c[u];
+        off += u < t ? cu : 0u;
+        total += cu;
+    }
+    __syncthreads();
+    if (sh_i[0] != 0 || total > (uint32_t)TG_CAP) {
+        if (t == 0) a.ovf[q] = 1u;
+        return;
+    }
+    for (uint32_t i = 0; i < c; ++i) {
+        const uint2 e = a.cand[(q * R + t) * TG_CAP_L + i];
+        ka[off + i] = topk_key(__uint_as_float(e.y), e.x);
+    }
+    __syncthreads();
+    const int n = (int)total;
+    // v16: the entry of rank min(16, n) - 1 among the approximate keys
+    const int want = (n < MAX_TOPK ? n : MAX_TOPK) - 1;
+    for (int e = t; e < n; e += 256) {
+        const unsigned long long key = ka[e];
+        int r = 0;
+        for (int u = 0; u < n; ++u) r += ka[u] > key ? 1 : 0;
+        if (r == want) *reinterpret_cast<unsigned long long*>(sh_i + 2) = key;
+    }
+    __syncthreads();
+    const float eps2 = a.theta[2 * q + 1];
+    const float lo = n > 0 ? topk_key_val(*reinterpret_cast<unsigned long long*>(sh_i + 2)) - eps2 : -INFINITY;
+    for (int e = t; e < n; e += 256) {
+        const unsigned long long key = ka[e];
+        if (topk_key_val(key) >= lo) {
+            const int pos = atomicAdd(sh_i + 1, 1);
+            if (pos < TG_CAP_X) kx[pos] = key;
+        }
+    }
+    __syncthreads();
+    const int nx = sh_i[1];
+    if (nx > TG_CAP_X) {
+        if (t == 0) a.ovf[q] = 1u;
+        return;
+    }
+    if (t == 0) a.ovf[q] = 0u;
+    unsigned long long key = 0ull;
+    if (t < nx) {
+        const uint32_t row = topk_key_row(kx[t]);
+        key = topk_key(topk_exact_dot(a.keys + (int64_t)row * KEY_DIM, sh_q), row);
+    }
+    __syncthreads();
+    kx[t] = key;
+    __syncthreads();
+    if (t < nx) {
+        int r = 0;
+        for (int u = 0; u < nx; ++u) r += kx[u] > key ? 1 : 0;      // (keys are unique: the row is part of the key)
+        if (r < a.k) {
+            a.oval[q * a.k + r] = topk_key_val(key);
+            a.oidx[q * a.k + r] = (int64_t)topk_key_row(key) + a.row_offset;
+        }
+    }
+    if (t >= nx && t < a.k) {                                       // (a bank with fewer than k rows)
+        a.oval[q * a.k + t] = -INFINITY;
+        a.oidx[q * a.k + t] = -1;
+    }
+}
+
+// more candidates than the lists hold (a bank of near-duplicates, or fewer than 16 row groups): every
+// row's float32 similarity (topk_stream.h: topk_brute_force).  A few workgroups walk the queries'
+// flags; normally none is set.
+__global__ __launch_bounds__(256) void topk_gemm_brute_kernel(TopkGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[KEY_DIM * 4 + 16 * MAX_TOPK * 8 + MAX_TOPK * 8];
+    float* sh_q = reinterpret_cast<float*>(lds);
+    unsigned long long* sh = reinterpret_cast<unsigned long long*>(lds + KEY_DIM * 4);
+    unsigned long long* res = sh + 16 * MAX_TOPK;
+    const int t = threadIdx.x;
+    for (int64_t q = blockIdx.x; q < a.B; q += gridDim.x) {
+        if (a.ovf[q] == 0u) continue;                                // (uniform over the workgroup)
+        __syncthreads();
+        sh_q[t] = a.ehat[q * KEY_DIM + t];
+        __syncthreads();
+        topk_brute_force(a.keys, a.n_valid, sh_q, sh, res);
+        if (t < a.k) {
+            const unsigned long long m = res[t];
+            a.oval[q * a.k + t] = m ? topk_key_val(m) : -INFINITY;
+            a.oidx[q * a.k + t] = m ? (int64_t)topk_key_row(m) + a.row_offset : (int64_t)-1;
+        }
+        if (t == 0 && a.exact_count) atomicAdd(a.exact_count, 1);
+    }
+}
+
+}  // namespace range_hip
