@@ -148,68 +148,104 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
     for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
     const uint32_t n_valid32 = (uint32_t)a.n_valid;
 
-    // what a tile's 4 x 4 approximate values per lane are used for
-    auto consume = [&](const f32x4 (&acc)[TG_GQ], int tile) __attribute__((always_inline)) {
-        const uint32_t row0 = (uint32_t)(t0 + tile * stride) * BLK;
-        const bool full = row0 + BLK <= n_valid32;          // (only the bank's last tile can hold pad rows)
+    // Only the bank's last tile can hold pad rows (zero keys: similarity 0, which must neither raise a
+    // group maximum nor become a candidate): it is kept out of the loop and handled behind it.
+    const bool tail_partial = stride == 1 ? (t1 == a.n_blocks && (a.n_valid % BLK) != 0)
+                                          : ((t0 + (b1 - 1) * stride) == a.n_blocks - 1 && (a.n_valid % BLK) != 0);
+    const int b1_main = b1 - (tail_partial ? 1 : 0);
+
+    // a tile's 4 x 8 MFMAs (its fragments from LDS or, for the tail tile, straight from memory)
+    auto mfma_tile = [&](const char* kt, f32x4 (&acc)[TG_GQ]) __attribute__((always_inline)) {
+        ts_u32x4 kf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const ts_u32x4*>(kt + c * 1024);
 #pragma unroll
         for (int gi = 0; gi < TG_GQ; ++gi) {
-            f32x4 s = acc[gi];
-            if (!full) {
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] = row0 + prow[r] < n_valid32 ? s[r] : -INFINITY;
-            }
-            const float m4 = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-            if (MODE == 0) {
-                if (tile & 1) mx[gi][1] = fmaxf(mx[gi][1], m4);
-                else mx[gi][0] = fmaxf(mx[gi][0], m4);
-            } else if (m4 >= th[gi] && qok[gi]) {
-                uint2* list = a.cand + (((q0 + gi * 16 + j) * a.n_splits + split) * 4 + g) * TG_CAP_L;
+            for (int c = 0; c < 8; ++c)
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ts_bf16x8, kf[c]),
+                                                             __builtin_bit_cast(ts_bf16x8, qf[gi][c]), c0, 0, 0, 0);
+            acc[gi] = c0;
+        }
+    };
+    // what a tile's 4 x 4 approximate values per lane are used for.  The common path is branch-free
+    // vector work (it sits in the same basic block as the NEXT tile's MFMAs, interleaved with them):
+    // pass A one v_max3 pair per group, pass B one compare per group; the append is ONE rare,
+    // wave-uniform branch per tile behind them.
+    auto consume = [&](f32x4 (&acc)[TG_GQ], int tile, int par, bool masked) __attribute__((always_inline)) {
+        const uint32_t row0 = (uint32_t)(t0 + tile * stride) * BLK;
+        if (masked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (s[r] >= th[gi]) {
-                        if (nc[gi] < (uint32_t)TG_CAP_L) list[nc[gi]] = make_uint2(row0 + prow[r], __float_as_uint(s[r]));
-                        ++nc[gi];
+            for (int gi = 0; gi < TG_GQ; ++gi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[gi][r] = row0 + prow[r] < n_valid32 ? acc[gi][r] : -INFINITY;
+        }
+        bool hit = false;
+#pragma unroll
+        for (int gi = 0; gi < TG_GQ; ++gi) {
+            const float m4 = fmaxf(fmaxf(acc[gi][0], acc[gi][1]), fmaxf(acc[gi][2], acc[gi][3]));
+            if (MODE == 0) mx[gi][par] = fmaxf(mx[gi][par], m4);
+            else hit = hit || m4 >= th[gi];
+        }
+        if (MODE == 1 && __builtin_amdgcn_ballot_w64(hit) != 0ull) {
+#pragma unroll
+            for (int gi = 0; gi < TG_GQ; ++gi) {
+                if (qok[gi]) {
+                    uint2* list = a.cand + (((q0 + gi * 16 + j) * a.n_splits + split) * 4 + g) * TG_CAP_L;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (acc[gi][r] >= th[gi]) {
+                            if (nc[gi] < (uint32_t)TG_CAP_L) list[nc[gi]] = make_uint2(row0 + prow[r], __float_as_uint(acc[gi][r]));
+                            ++nc[gi];
+                        }
                     }
                 }
             }
         }
     };
+    // one MFMA, two vector instructions, ... : the order the 32 MFMAs of a tile and the vector work of
+    // the previous tile's values are issued in
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8 * TG_GQ; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+    };
 
-    f32x4 prev[TG_GQ];
-    int prev_tile = -1;
+    // two tiles per phase: tile 2p -> accA (parity 0), tile 2p + 1 -> accB (parity 1); a tile's values are
+    // consumed one tile later, beside the next tile's MFMAs
+    f32x4 accA[TG_GQ], accB[TG_GQ];
+    bool have_b = false;
+    const int n_phase_main = (b1_main + TG_KT - 1) / TG_KT;
     for (int p = 0; p < n_phase; ++p) {
         // phase p has landed when at most the 4 operations of phase p + 1 are outstanding (own share;
         // the barrier makes it everybody's); every wave is then also done reading phase p - 1, whose
         // slot phase p + 2 takes
         asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         issue(p + 2);
+        if (p >= n_phase_main) continue;                     // (a last phase that held only the tail tile)
         const char* slot = smem + (p % TG_SLOTS) * TG_KT * TSB_TILE_BYTES + lane * 16;
-#pragma unroll
-        for (int t = 0; t < TG_KT; ++t) {
-            const int tile = b0 + p * TG_KT + t;
-            if (tile >= b1) break;
-            ts_u32x4 kf[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const ts_u32x4*>(slot + t * TSB_TILE_BYTES + c * 1024);
-            f32x4 acc[TG_GQ];
-#pragma unroll
-            for (int gi = 0; gi < TG_GQ; ++gi) {
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ts_bf16x8, kf[c]),
-                                                                 __builtin_bit_cast(ts_bf16x8, qf[gi][c]), c0, 0, 0, 0);
-                acc[gi] = c0;
-            }
-            // the previous tile's values, in the shadow of this tile's chains
-            if (prev_tile >= 0) consume(prev, prev_tile);
-#pragma unroll
-            for (int gi = 0; gi < TG_GQ; ++gi) prev[gi] = acc[gi];
-            prev_tile = tile;
+        mfma_tile(slot, accA);
+        if (have_b) consume(accB, 2 * p - 1, 1, false);
+        interleave();
+        if (2 * p + 1 < b1_main) {
+            mfma_tile(slot + TSB_TILE_BYTES, accB);
+            consume(accA, 2 * p, 0, false);
+            interleave();
+            have_b = true;
+        } else {
+            consume(accA, 2 * p, 0, false);
+            have_b = false;
         }
     }
-    if (prev_tile >= 0) consume(prev, prev_tile);
+    if (have_b) consume(accB, 2 * n_phase_main - 1, 1, false);
+    if (tail_partial) {
+        const int tile = b1 - 1;
+        mfma_tile(kb + ((int64_t)t0 + (int64_t)tile * stride) * TSB_TILE_BYTES + lane * 16, accA);
+        consume(accA, tile, tile & 1, true);
+    }
     // the clamped prefetches of the last phases are still in flight into this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -257,6 +293,29 @@ __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* _
     }
 }
 
+// topk_exact_dot (topk_stream.h) - the same products in the same order, the same float - with the key
+// row's loads issued in two bursts of 32 instead of sixteen dependent groups of four: a thread that
+// walks a row of its own pays the memory latency twice, not sixteen times
+__device__ __forceinline__ float topk_exact_dot_burst(const float* __restrict__ kr, const float* sh_q) {
+    float acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 kc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) kc[i] = *reinterpret_cast<const f32x4*>(kr + 128 * h + 4 * i);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    acc = __builtin_fmaf(kc[4 * s8 + gg][c], sh_q[128 * h + 16 * s8 + 4 * gg + c], acc);
+            }
+        }
+    }
+    return acc;
+}
+
 // The candidates of one query -> its top k: one workgroup per query.
 //   1. the lists' lengths (n_splits x 4 of them), a prefix sum, the entries compacted into LDS as
 //      64-bit keys (ordered bits of S~, ~row);
@@ -266,7 +325,7 @@ __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* _
 // A query with a list that overflowed, more than TG_CAP candidates or more than TG_CAP_X in step 3 is
 // handed to topk_gemm_brute_kernel.
 constexpr int TG_RR_LDS = KEY_DIM * 4 + TG_CAP * 8 + 256 * 4 + TG_CAP_X * 8 + 32;
-__global__ __launch_bounds__(256, 4) void topk_gemm_rerank_kernel(TopkGemmArgs a) {
+__global__ __launch_bounds__(256, 2) void topk_gemm_rerank_kernel(TopkGemmArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[TG_RR_LDS];
     float* sh_q = reinterpret_cast<float*>(lds);
     unsigned long long* ka = reinterpret_cast<unsigned long long*>(lds + KEY_DIM * 4);     // [TG_CAP] approximate keys
@@ -293,9 +352,17 @@ __global__ __launch_bounds__(256, 4) void topk_gemm_rerank_kernel(TopkGemmArgs a
         if (t == 0) a.ovf[q] = 1u;
         return;
     }
-    for (uint32_t i = 0; i < c; ++i) {
-        const uint2 e = a.cand[(q * R + t) * TG_CAP_L + i];
-        ka[off + i] = topk_key(__uint_as_float(e.y), e.x);
+    // (all threads walk the lists' slots side by side: the loads are independent and a list's entries
+    // sit next to each other; one thread per list walking its entries paid a memory latency per entry)
+    sh_c[t] = t < R ? ((c << 16) | off) : 0u;                        // (both <= TG_CAP: 11 bits each)
+    __syncthreads();
+    for (int e = t; e < R * TG_CAP_L; e += 256) {
+        const int r = e / TG_CAP_L, i = e - r * TG_CAP_L;
+        const uint32_t co = sh_c[r];
+        if ((uint32_t)i < (co >> 16)) {
+            const uint2 v = a.cand[(q * R + r) * TG_CAP_L + i];
+            ka[(co & 0xFFFFu) + i] = topk_key(__uint_as_float(v.y), v.x);
+        }
     }
     __syncthreads();
     const int n = (int)total;
@@ -327,7 +394,7 @@ __global__ __launch_bounds__(256, 4) void topk_gemm_rerank_kernel(TopkGemmArgs a
     unsigned long long key = 0ull;
     if (t < nx) {
         const uint32_t row = topk_key_row(kx[t]);
-        key = topk_key(topk_exact_dot(a.keys + (int64_t)row * KEY_DIM, sh_q), row);
+        key = topk_key(topk_exact_dot_burst(a.keys + (int64_t)row * KEY_DIM, sh_q), row);
     }
     __syncthreads();
     kx[t] = key;
