@@ -748,32 +748,38 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
                 e.close()
         del keys_dev
     # the north star's own sentence: the top-k similarity scan over range_db_large for the 10 000-query
-    # batch (``model.topk``: 313 passes of two query groups over the bf16 keys in ONE stream launch + the
-    # merge launch).  At this batch size the scan is not a stream any more: the 51 MB copy of the keys sits
-    # in the Infinity Cache and a pass is bound by its list maintenance and by what the passes cost at
-    # their seams (query operands, the publish of every supergroup) - reported for completeness.
+    # batch (``model.topk``).  Beyond 256 queries the scan is GEMM-shaped (range_amd/csrc/topk_gemm.h,
+    # round 5): bf16 MFMA products of every (query, key) pair - a sampled pass for per-query thresholds,
+    # a full pass that appends the candidates, a float32 re-rank; values and indices are those of the
+    # float32 scan bit for bit.  Its bound is the bf16 MFMA peak, not HBM: the 51 MB of bf16 keys sit in
+    # the Infinity Cache.  ``frac`` = the ALGORITHMIC products 2 x 256 x B x N / time / 2.5 PFLOP/s;
+    # ``executed_flop`` adds the sampled pass (1 / TG_SAMPLE of a pass).
     nq = 10_000
     x = torch.from_numpy(synth.make_queries(nq, seed=7, lat_max=90.0)).to(dev)
     _, e32, _ = eng.encode(x)
-    for _ in range(2):
+    for _ in range(20):            # (also the pre-heat: 20 x ~0.9 ms)
         eng.topk_stream(e32, 16)
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.profile_enable(True)
     t0.record()
-    for _ in range(5):
+    for _ in range(20):
         eng.topk_stream(e32, 16)
     t1.record()
     t1.synchronize()
-    us = t0.elapsed_time(t1) / 5 * 1e3
-    passes = ((nq + 15) // 16 + 1) // 2
-    streamed = passes * N * KEY_ROW_BYTES // 2
-    out.append({"kernel": "topk_stream_bf16_kernel<2 groups of 16 queries per pass> + topk_merge_kernel (two launches)",
-                "keys": "bf16", "bank_rows": N, "resident": "infinity_cache", "queries": nq, "passes": passes,
-                "streamed_bytes": streamed, "us_per_call": us, "us_source": "5 calls between one HIP event pair",
-                "streamed_TBps": streamed / (us * 1e-6) / 1e12, "peak_TBps": PEAK_HBM_GBS / 1e3,
-                "frac": streamed / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+    us = t0.elapsed_time(t1) / 20 * 1e3
+    scan_us, rerank_us = eng.profile_read(_native.PROF_TOPK_STREAM)[0] / 20 * 1e3, eng.profile_read(_native.PROF_TOPK_MERGE)[0] / 20 * 1e3
+    eng.profile_enable(False)
+    flop = 2.0 * 256 * nq * N
+    out.append({"kernel": "topk_gemm_kernel<0> (sampled group maxima) + threshold + topk_gemm_kernel<1> (candidates) + "
+                          "topk_gemm_rerank_kernel (float32 re-rank): range_amd/csrc/topk_gemm.h",
+                "keys": "bf16", "bank_rows": N, "resident": "infinity_cache", "queries": nq,
+                "us_per_call": us, "us_source": "20 calls between one HIP event pair, after 20 untimed ones",
+                "us_scan_kernels": scan_us, "us_rerank": rerank_us,
+                "bound": "mfma bf16", "algorithmic_flop": flop, "executed_flop": flop * 1.25,
+                "achieved_tflops": flop / (us * 1e-6) / 1e12, "peak_tflops": 2500.0,
+                "frac": flop / (us * 1e-6) / 1e12 / 2500.0,
                 "queries_per_s": nq / (us * 1e-6), "product_path": True,
-                "note": "the bench's own batch; not HBM-bound (keys resident in the Infinity Cache, a pass bound by "
-                        "list maintenance and pass seams): frac is bytes re-streamed per pass / time / 8 TB/s",
+                "round4_streaming_scan_us": 3890.0,
                 "exact_fallback_queries": eng.topk_stream_exact_count()})
     return out
 
