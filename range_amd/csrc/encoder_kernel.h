@@ -92,6 +92,7 @@ struct EncArgs {
     uint32_t* sync;
     uint32_t* err;              // host-mapped word (or null): set when a bounded in-kernel wait gave up
     int32_t debug_giveup;       // test hook: every in-launch wait behaves as if it had expired
+    int32_t skip_fill;          // encoder_tile_kernel, a workgroup's 2nd.. part of a phase: its input is in LDS already
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -227,8 +228,8 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
     }
 }
 
-#ifdef RANGE_EXP_ENC_STAMPS   // tuning only: phase stamps of workgroup 0 / thread 0 behind e3's 16 rows (100 MHz counter)
-#define ENC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.e3) reinterpret_cast<unsigned long long*>(a.e3 + 16 * ENC_EMBED)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef RANGE_EXP_ENC_STAMPS   // tuning only: phase stamps of workgroup 0 / thread 0 behind e3's rows (100 MHz counter)
+#define ENC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.e3) reinterpret_cast<unsigned long long*>(a.e3 + ((a.B + 15) / 16) * 16 * ENC_EMBED)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ENC_STAMP(i) do { } while (0)
 #endif
@@ -443,7 +444,9 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         return;
     }
     const int l0 = MODE == 2 ? a.rest_from : 0;   // first layer whose activation is already in LDS
-    if ((MODE == 2 && l0 == 1) || MODE == 4) {
+    if ((MODE == 3 || MODE == 4) && a.skip_fill) {
+        // (the previous part of this phase left the tile's input in LDS)
+    } else if ((MODE == 2 && l0 == 1) || MODE == 4) {
         // the activated second layer of this tile, written by the MODE 3 workgroups
         for (int idx = tid; idx < QT * 16 * a.H; idx += blockDim.x) {
             const int q = idx / a.H, k = idx - q * a.H;
@@ -777,8 +780,10 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // The first K = max(workgroups of any later phase) workgroups stay to the end and meet at every
     // counter, whether or not a phase has work for them (narrow encoders: 2 workgroups activate, 2 run
     // the second layer, but 4 the last one); the others leave after the first layer.
+    // (up to 512 queries a tile has at least that many workgroups; beyond - 513 .. 2 048 queries, round 5:
+    // 2-7 workgroups per tile - ALL of a tile's workgroups stay and take the parts of a phase in turns)
     const int n_act = (16 * a.H + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int K = max(max(n_act, a.n_parts2), 4);
+    const int K = min(n_wg, max(max(n_act, a.n_parts2), 4));
     // a phase hand-off; a workgroup that leaves because its wait gave up: workgroup 0 of the tile (a
     // consumer of every phase, and the only writer of the results) leaves NaN rows behind
 #define ENC_HANDOFF(ctr, n_prod, n_cons, consumer)                                              \
@@ -791,8 +796,8 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     } while (0)
     ENC_HANDOFF(sync, n_wg, K, b < K);
     ENC_STAMP(2);
-    if (b < n_act) {
-        const int e = b * (int)blockDim.x + (int)threadIdx.x;
+    for (int blk = b; blk < n_act; blk += K) {
+        const int e = blk * (int)blockDim.x + (int)threadIdx.x;
         if (e < 16 * a.H) {
             const int q = e / a.H, k = e - q * a.H;
             const int64_t at = (q0 + q) * a.H + k;
@@ -805,12 +810,24 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // ---- second layer on the first n_parts2 workgroups
     ENC_HANDOFF(sync + 64, K, K, true);
     ENC_STAMP(4);
-    if (b < a.n_parts2) encoder_body<1, 4, 1, 3>(a, q0, smem, b);
+    // (parts of 64 columns with K split four ways where a tile has >= H / 64 workgroups; wider parts -
+    // 128 or 256 columns, one n-tile per wave over the whole K - where it has fewer: the host chooses)
+    for (int part = b; part < a.n_parts2; part += K) {
+        EncArgs a3 = a;
+        a3.skip_fill = part != b;
+        if (a.part2_cols == 64) encoder_body<1, 4, 1, 3>(a3, q0, smem, part);
+        else if (a.part2_cols == 128) encoder_body<2, 8, 1, 3>(a3, q0, smem, part);
+        else encoder_body<4, 16, 1, 3>(a3, q0, smem, part);
+    }
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
     ENC_HANDOFF(sync + 128, K, K, true);
     ENC_STAMP(6);
-    if (b < 4) encoder_body<4, 4, 1, 4>(a, q0, smem, b);
+    for (int part = b; part < 4; part += K) {
+        EncArgs a4 = a;
+        a4.skip_fill = part != b;
+        encoder_body<4, 4, 1, 4>(a4, q0, smem, part);
+    }
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
     ENC_HANDOFF(sync + 192, K, 1, b == 0);

@@ -114,6 +114,7 @@ struct range_ctx {
     uint32_t* h_async_err = nullptr;
     uint32_t* d_async_err = nullptr;
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
+    bool enc_fused_mid = true;      // RANGE_ENC_FUSED_MID=0: 513 .. 2 048 queries as three launches (A/B)
     int last_qtiles = 0, last_splits = 0;
     bool p2_streamk = true;         // RANGE_P2_STREAMK=0: pass 2 as one workgroup per (bank split, query tile) (A/B)
     int p2_col_rows = 16384;        // RANGE_P2_COL_ROWS=n: largest bank column of the stream-K walk (rows; tuning)
@@ -191,10 +192,21 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     // up to 32 tiles (512 queries): all phases in ONE launch (encoder_tile_kernel), every tile on its own
     // workgroups, where a tile's first-layer workgroups are enough to carry its later phases (H / 64 of
     // them the second layer, 4 the last)
-    if (tiles <= 32 && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 &&
-        S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024) && tiles * S * KP <= c->n_cu) {
+    // ... and, round 5, more tiles while a tile still gets >= 5 workgroups (up to 51 tiles = 816 queries):
+    // those take the parts of the later phases in turns - 513 queries 100 us instead of 114 as three
+    // launches, 625 queries 104 instead of 116.  Beyond (2-3 workgroups per tile: a rank's 1 250 queries
+    // of an 8-GPU batch, a large batch's last partial round) the one launch measured SLOWER - 1 250
+    // queries 155-159 us against 132, 2 048 queries 190 against 157 (tools/encoder_mid.py) - and stays
+    // three launches.  Phase stamps of tile 0 at 1 250 queries (us): first layer 51, wait 12, activation
+    // 4, second layer 22 (6 of them filling LDS), wait 10, last layer 41 (two parts of 64 outputs, one
+    // after the other: each streams 256 KB of weights + 64 KB of input into ONE CU, ~20 us), norm 3: the
+    // later phases are bound by what a single CU can pull, and the separate launches spread them over
+    // more CUs (RANGE_ENC_FUSED_MID=0: three launches everywhere, A/B).
+    const bool few_tiles = tiles <= 32 && S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024);
+    const bool mid_tiles = tiles > 32 && tiles <= 128 && S * KP >= 5 && c->enc_fused_mid;
+    if ((few_tiles || mid_tiles) && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 && a.H <= 512 && tiles * S * KP <= c->n_cu) {
         if (c->ws_h2.ensure((size_t)tiles * 16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)tiles * 16 * a.H) != hipSuccess ||
-            c->ws_e3.ensure((size_t)tiles * 16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(32 * 256) != hipSuccess)
+            c->ws_e3.ensure((size_t)tiles * 16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(128 * 256) != hipSuccess)
             return fail(RANGE_ERR_NOMEM, "out of device memory");
         // (the counters wrap to zero by themselves, but a launch whose bounded spin gave up would leave
         // them poisoned for good: zeroed in front of every launch - 2 us of a ~55 us kernel - as the
@@ -207,8 +219,10 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         a.err = c->d_async_err ? c->d_async_err + RANGE_ASYNC_WORD_ENCODER : nullptr;
         a.debug_giveup = c->debug_giveup_next ? 1 : 0;
         c->debug_giveup_next = false;
-        a.n_parts2 = a.H / 64;
+        // second-layer parts: 64 columns where the tile has a workgroup for each, else 128 / 256
         a.part2_cols = 64;
+        while (a.part2_cols < 256 && S * KP < a.H / a.part2_cols && a.H % (2 * a.part2_cols) == 0) a.part2_cols *= 2;
+        a.n_parts2 = a.H / a.part2_cols;
         a.rest_from = 1;
 #define RANGE_ENC_TILE(NTP, NWP)                                                               \
     case NTP:                                                                                  \
@@ -229,7 +243,7 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
         if (std::getenv("RANGE_ENC_STAMPS")) {
             unsigned long long h[12];
             HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(h, c->ws_e3.p + 16 * ENC_EMBED, sizeof h, hipMemcpyDeviceToHost));   // (one tile: the stamps sit behind its 16 rows)
+            HIP_TRY(hipMemcpy(h, c->ws_e3.p + (size_t)tiles * 16 * ENC_EMBED, sizeof h, hipMemcpyDeviceToHost));   // (the stamps sit behind the tiles' rows)
             std::fprintf(stderr, "encoder_tile stamps (us after start):");
             for (int i = 1; i < 12; ++i) std::fprintf(stderr, " %d: %.1f", i, (double)(h[i] - h[0]) * 0.01);
             std::fprintf(stderr, "  [1 first layer, 2 sync, 3 activation, 4 sync, 5 second layer (10 its input in LDS, 11 its products), "
@@ -521,6 +535,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_ENC_SPLIT2")) c->enc_split2 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_SPLIT3")) c->enc_split3 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_FUSED")) c->enc_fused = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_FUSED_MID")) c->enc_fused_mid = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_TAIL")) c->enc_tail_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';
