@@ -527,10 +527,12 @@ def rank_main(a, rank, local, world, backend):
     scan = None
     host_contract = None
     opt_in = None
+    envelope = None
     if world == 1 and not sharded and not a.no_extras and default_workload:
         scan = scan_roofline(eng, synth, torch, dev, N, bank)
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
         opt_in = opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev)
+        envelope = kept_logits_envelope(measure, a, torch, dev, enc, table, bank, N, L, H)
 
     if rank == 0:
         att_ms, att_n = m["prof"]["attend"]
@@ -595,6 +597,10 @@ def rank_main(a, rank, local, world, backend):
                          "traffic_per_step": None if pmc_entry is None else pmc_entry.get("hbm_bytes_per_step"),
                          "traffic_per_step_over_hbm_minimal":
                              None if pmc_entry is None else pmc_entry.get("hbm_bytes_per_step_over_survey_minimal"),
+                         # the logits pass 1 keeps for pass 2 (4 B per (query, bank row) of a call): what they
+                         # cost, where keeping stops, and what the step makes without them
+                         "kept_logits_bytes": (((q_per_launch + 63) // 64) * ((n_local + 15) // 16) * 4096) if kept else 0,
+                         **({} if envelope is None else envelope),
                          "avg_launch_ms": att_avg_ms, "launches": att_n,
                          "queries_per_launch": q_per_launch,
                          "flop_per_launch": flops,
@@ -643,6 +649,60 @@ def rank_main(a, rank, local, world, backend):
         dist.barrier()
         if backend != "threads":
             dist.destroy_process_group()
+
+
+def kept_logits_envelope(measure, a, torch, dev, enc, table, bank, N, L, H):
+    """The envelope of the kept-logit scheme (pass 1 writes 4 B per (query, bank row), pass 2 reads
+    them back instead of recomputing e . K^T: 25 % fewer MFMAs in pass 2 for 20x the HBM-minimal
+    traffic of the step - the right trade while the step is MFMA-bound):
+      keep_switch_off  a call keeps its logits while they fit in HALF of the free device memory
+                       (include/range_hip.h: range_scan_stats); beyond, pass 2 recomputes
+      recompute_path   the same step with keeping switched off (RANGE_KEEP_LOGITS=0), on this bank and
+                       on a DRAM-sized one (N = 10^6 rows: 5.1 GB of bank, generated on the device),
+                       where the kept logits of a 10 000-query step are 40 GB."""
+    import numpy as np
+    from range_amd import _native
+    from range_amd.bank import PreparedBank
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    out = {"keep_switch_off": {"rule": "logits of a call are kept while 4 B x queries x bank rows <= half of the free device memory",
+                               "free_bytes_now": int(free_b), "max_pairs_kept": int(free_b // 8),
+                               "queries_per_call_at_this_bank": int(free_b // 8 // N),
+                               "queries_per_call_at_1e6_rows": int(free_b // 8 // 1_000_000)}}
+
+    def engine(keep, b):
+        if not keep:
+            os.environ["RANGE_KEEP_LOGITS"] = "0"          # read at range_create
+        try:
+            e = _native.HipEngine(dev)
+        finally:
+            os.environ.pop("RANGE_KEEP_LOGITS", None)
+        e.set_encoder(L, H, 2, 256, _native.SH_ANALYTIC, enc.weights, enc.biases, sh_table=table)
+        e.set_bank(b.keys, b.values, b.xyz, 0)
+        return e
+
+    steps = max(3, a.steps // 4)
+    e0 = engine(False, bank)
+    m = measure(a.scaling, steps, 1, eng=e0, model=None, sharded=False)
+    rec = {"this_bank": {"bank_rows": N, "value": m["B"] * steps / m["dt"], "ms_per_step": m["dt"] / steps * 1e3,
+                         "kept": bool(m["kept"])}}
+    e0.close()
+    # a DRAM-sized bank: the values (4.1 GB) no longer sit in the 256 MB Infinity Cache
+    n_big = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(77)
+    keys = torch.nn.functional.normalize(torch.randn((n_big, 256), generator=g, device=dev), dim=1)
+    vals = torch.randn((n_big, 1024), generator=g, device=dev)
+    xyz = torch.nn.functional.normalize(torch.randn((n_big, 3), generator=g, device=dev), dim=1)
+    big = PreparedBank(keys.cpu().numpy(), vals.cpu().numpy(), xyz.cpu().numpy())
+    del keys, vals, xyz
+    for keep in (True, False):
+        e1 = engine(keep, big)
+        m = measure(a.scaling, steps, 1, eng=e1, model=None, sharded=False)
+        rec[f"rows_1e6_{'kept' if keep else 'recompute'}"] = {
+            "bank_rows": n_big, "value": m["B"] * steps / m["dt"], "ms_per_step": m["dt"] / steps * 1e3,
+            "kept": bool(m["kept"]), "kept_logits_bytes": int(((m["B"] + 63) // 64) * ((n_big + 15) // 16) * 4096) if m["kept"] else 0}
+        e1.close()
+    out["recompute_path"] = rec
+    return out
 
 
 def opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev):

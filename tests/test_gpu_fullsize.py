@@ -273,3 +273,46 @@ def test_c5_beta_sweep_one_million_queries(tmp_path):
     lo = 16384 * 7
     again = m.sweep(x[lo:lo + 16384], betas, return_device=True)
     assert torch.equal(again, sw[:, lo:lo + 16384])
+
+
+@pytest.mark.parametrize("keep", [True, False])
+def test_dram_sized_bank_through_load_model(keep, tmp_path, monkeypatch):
+    """N = 10^6 rows (5.1 GB of bank: ten times range_db_large, the values far beyond the 256 MB
+    Infinity Cache) through ``load_model(...)`` on BOTH forms of pass 2 - on the logits pass 1 kept
+    (16 GB for the 4 096 queries of a call) and recomputing them (RANGE_KEEP_LOGITS=0: what a call
+    does whose logits no longer fit in half of the free memory): every row through the
+    planted-column properties, a sample against the float64 oracle over the whole bank.  (The bank
+    is generated on the device and handed to ``load_model`` in place of the file reader: no 5 GB file.)"""
+    import range_amd.range as R
+    from range_amd.bank import PreparedBank
+    N, B = 1_000_000, 4096
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    keys = torch.nn.functional.normalize(torch.randn((N, 256), generator=g, device=dev), dim=1)
+    vals = torch.randn((N, 1024), generator=g, device=dev)
+    vals[:, 0] = 1.0
+    vals[:, 1] = -2.5
+    lon = torch.rand(N, generator=g, device=dev, dtype=torch.float64) * 360 - 180
+    lat = torch.asin(torch.rand(N, generator=g, device=dev, dtype=torch.float64) * 2 - 1) * 180 / np.pi
+    rad = torch.stack([lon, lat], 1).float() * np.float32(np.pi / 180)
+    xyz = torch.stack([torch.cos(rad[:, 1]) * torch.cos(rad[:, 0]), torch.cos(rad[:, 1]) * torch.sin(rad[:, 0]), torch.sin(rad[:, 1])], 1)
+    bank = PreparedBank(keys.cpu().numpy(), vals.cpu().numpy(), xyz.float().cpu().numpy())
+    del keys, vals, xyz, rad
+    torch.cuda.empty_cache()
+    monkeypatch.setattr(R, "load_bank", lambda path: bank)
+    if not keep:
+        monkeypatch.setenv("RANGE_KEEP_LOGITS", "0")
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
+    m = load_model("RANGE+", pretrained_path=ck, device="cuda:0", db_path="in-memory", beta=0.5)
+    q = synth.make_queries(B, seed=3, lat_max=90.0)
+    out = m(torch.from_numpy(q).to(dev), return_device=True)
+    assert out.shape == (B, 1280) and bool(torch.isfinite(out).all())
+    assert (m.engine.kept_queries() == B) == keep
+    # float32 sums over 10^6 weights: the worst of 4 096 rows (tools/big_bank.py)
+    assert float((out[:, 0] - 1.0).abs().max()) < 5e-5 and float((out[:, 1] + 2.5).abs().max()) < 1e-4
+    assert float((out[:, 1024:].norm(dim=1) - 1.0).abs().max()) < 1e-12
+    idx = np.linspace(0, B - 1, 12).astype(np.int64)
+    got = out[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    obank = O.Bank(bank.keys, bank.values, bank.xyz)
+    ref64 = O.retrieve64(got[:, 1024:], q[idx], obank, "RANGE+", 0.5)
+    assert float(np.abs(got[:, :1024] - ref64).max()) < 2e-5
