@@ -206,14 +206,10 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
 
 
 def csrc_sha256():
-    """SHA-256 over the sources of librange_hip.so (as profiles/make_attend_pmc.py stamps them)."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(REPO, "range_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        h.update(name.encode())
-        h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()
+    """SHA-256 over the sources of librange_hip.so (range_amd/_srchash.py: what build.sh embeds in the
+    library and profiles/make_attend_pmc.py stamps the counter passes with)."""
+    from range_amd._srchash import source_sha256
+    return source_sha256()
 
 
 def pmc_traffic(kernel, B, N, qt, ns):

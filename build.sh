@@ -12,6 +12,8 @@ obj=$(mktemp -d)
 trap 'rm -rf "$obj"' EXIT
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
 printf '#define RANGE_BUILD_FLAGS "%s"\n' "$*" > "$obj/range_build_flags.h"
+# the hash of the sources this library is built from (range_amd/_srchash.py): range_source_sha256()
+printf '#define RANGE_SRC_SHA256 "%s"\n' "$(python3 range_amd/_srchash.py)" >> "$obj/range_build_flags.h"
 hipcc $flags "$@" -include "$obj/range_build_flags.h" -c range_amd/csrc/range_hip.hip -o "$obj/range_hip.o" &
 pid=$!
 hipcc $flags "$@" -c range_amd/csrc/probe_hip.hip -o "$obj/probe_hip.o"

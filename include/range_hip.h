@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 7
+#define RANGE_ABI_VERSION 8
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -67,6 +67,9 @@ const char* range_last_error(void);
  * default build.  A build carrying RANGE_EXP_* switches is a timing experiment whose results are
  * invalid: the Python binding refuses to load it. */
 const char* range_build_flags(void);
+/* SHA-256 (hex) of the sources this library was built from (range_amd/_srchash.py; build.sh embeds
+ * it): the binding refuses a library whose stamp is not the checkout's, __graft_entry__.build() rebuilds. */
+const char* range_source_sha256(void);
 
 /* Create / destroy an engine context on GPU `device`. */
 int range_create(int device, range_ctx** out);

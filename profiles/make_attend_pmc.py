@@ -16,13 +16,10 @@ SURVEY_HBM_MINIMAL_BYTES = 100_000 * 5132 + 10_000 * (16 + 10_240)     # SURVEY.
 
 
 def csrc_sha256():
-    """SHA-256 over the kernel and host sources of librange_hip.so (names and contents, sorted)."""
-    h = hashlib.sha256()
-    d = os.path.join(REPO, "range_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        h.update(name.encode())
-        h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()
+    """the hash build.sh embeds in the library and bench.py compares against (range_amd/_srchash.py)"""
+    sys.path.insert(0, REPO)
+    from range_amd._srchash import source_sha256
+    return source_sha256()
 
 
 def hbm_bytes(k):

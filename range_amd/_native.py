@@ -28,7 +28,7 @@ COORD_DIMS = {COORD_DIRECT: 2, COORD_CARTESIAN3D: 3, COORD_WRAP: 4}
 
 # every symbol include/range_hip.h declares
 SYMBOLS = (
-    "range_abi_version", "range_last_error", "range_build_flags", "range_create", "range_destroy", "range_set_encoder",
+    "range_abi_version", "range_last_error", "range_build_flags", "range_source_sha256", "range_create", "range_destroy", "range_set_encoder",
     "range_set_sh_table",
     "range_set_bank", "range_bank_rows", "range_encode", "range_scan_stats", "range_merge_stats",
     "range_merge_topk", "range_attend", "range_finalize", "range_forward",
@@ -111,8 +111,18 @@ def load_library() -> C.CDLL:
     lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 7:
+    if lib.range_abi_version() != 8:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
+    # the library must be built from THIS checkout's sources (a stale in-tree .so travels with the
+    # snapshot: it is git-ignored, not gpurun-ignored); RANGE_LIB_PATH builds (tuning) are exempt
+    lib.range_source_sha256.restype = C.c_char_p
+    if not os.environ.get("RANGE_LIB_PATH"):
+        from ._srchash import source_sha256
+        built, here = lib.range_source_sha256().decode(), source_sha256()
+        if built != here:
+            raise RangeNativeError(
+                f"{LIB_PATH} was built from other sources (stamp {built[:12]}, this checkout {here[:12]}): "
+                "rebuild with ./build.sh or __graft_entry__.build()")
     flags = lib.range_build_flags().decode()
     if "RANGE_EXP_" in flags and os.environ.get("RANGE_ALLOW_EXPERIMENT_BUILD") != "1":
         raise RangeNativeError(

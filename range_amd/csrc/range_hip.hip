@@ -511,6 +511,12 @@ const char* range_last_error(void) { return g_err.c_str(); }
 #define RANGE_BUILD_FLAGS ""
 #endif
 const char* range_build_flags(void) { return RANGE_BUILD_FLAGS; }
+#ifndef RANGE_SRC_SHA256
+#define RANGE_SRC_SHA256 "unknown"
+#endif
+// (the literal is also what range_amd/_srchash.py: library_stamp() finds in the file without loading it)
+static const char g_src_stamp[] = "RANGE_SRC_SHA256=" RANGE_SRC_SHA256;
+const char* range_source_sha256(void) { return g_src_stamp + 17; }
 
 int range_create(int device, range_ctx** out) {
     if (!out) return fail(RANGE_ERR_INVALID, "out is null");

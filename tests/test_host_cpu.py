@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.range_abi_version() == 7
+    assert lib.range_abi_version() == 8
     assert lib.range_last_error() is not None
     # the ridge-probe header, same library
     from range_amd import _probe_native
