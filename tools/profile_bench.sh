@@ -12,8 +12,6 @@ tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
-python $R/bench.py > $O/bench.log 2> $O/bench.err
-tail -1 $O/bench.log > $O/bench_line.json
 cd /tmp && export TMPDIR=/tmp
 # (--no-extras: only the timed workload, so that per-kernel averages are those of the bench geometry)
 B="python3 $R/bench.py --cpu-sample 0 --no-extras"
@@ -23,11 +21,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2 -o p --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc3 -o p -- $B --steps 3 --warmup 1 > $O/p3.log 2>&1
 python3 $R/profiles/pmc_summarize.py $O/pmc1 $O/pmc2 $O/pmc3 > $O/pmc_summary.json
 # the traffic figures bench.py reports, stamped with the hash of the kernel sources measured (copy to profiles/attend_pmc.json)
-python3 $R/profiles/make_attend_pmc.py $O/pmc_summary.json $O/bench_line.json $tag > $O/attend_pmc.json
+python3 $R/bench.py --no-extras --cpu-sample 0 2> /dev/null | tail -1 > $O/bench_line_noextras.json
+python3 $R/profiles/make_attend_pmc.py $O/pmc_summary.json $O/bench_line_noextras.json $tag > $O/attend_pmc.json
+# the bench line proper, with the traffic of the passes above (stamped with this checkout's source hash)
+cp $O/attend_pmc.json $R/profiles/attend_pmc.json
+(cd $R && python3 bench.py > $O/bench.log 2> $O/bench.err)
+tail -1 $O/bench.log > $O/bench_line.json
 find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 echo "bench passes done"
 mkdir -p $O/scan
-for n in 100000 1000000; do for q in 16 64; do for k in bf16 f32; do
+for n in 100000 1000000; do for q in 16 32 64; do for k in bf16 f32; do
   rocprofv3 --kernel-trace --output-format csv -d $O/scan/ks_${n}_${q}_${k} -o t -- python3 $R/tools/scan_bench.py --n $n --q $q --keys $k > $O/scan/ks_${n}_${q}_${k}.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan/pmc_${n}_${q}_${k} -o p -- python3 $R/tools/scan_bench.py --n $n --q $q --keys $k > $O/scan/pmc_${n}_${q}_${k}.log 2>&1
   echo "scan $n $q $k done"
@@ -36,5 +39,16 @@ python3 $R/profiles/scan_summarize.py $O/scan > $O/scan_summary.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -o lat -- python3 $R/tools/latency.py > $O/latency.log 2>&1
 find $O/lat -name "*kernel_stats.csv" -exec cp {} $O/latency_kernel_stats.csv \;
 python3 $R/tools/latency.py > $O/latency_plain.log 2>&1
+# round 5: the batch-scale top-k (kernel trace), what a rank of 8 computes (steady state / the old cold
+# protocol / layouts), the clock ramp behind the difference, the mid-size encoder A/B
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/topk -o tk -- python3 $R/tools/topk_batch.py 10000 100000 > $O/topk_batch.log 2>&1
+find $O/topk -name "*kernel_stats.csv" -exec cp {} $O/topk_batch_kernel_stats.csv \;
+python3 $R/tools/shard_emulate.py 1 8 > $O/shard_emulate_steady.log 2>&1
+python3 $R/tools/shard_emulate.py --chunks 1 8 > $O/shard_emulate_one_chunk.log 2>&1
+python3 $R/tools/shard_emulate.py --cold 8 > $O/shard_emulate_cold_protocol.log 2>&1
+python3 $R/tools/shard_emulate.py --layouts 8 > $O/shard_emulate_layouts.log 2>&1
+python3 $R/tools/clock_ramp.py 10000 12500 300 > $O/clock_ramp.log 2>&1
+python3 $R/tools/clock_ramp.py 10000 12500 100 3 >> $O/clock_ramp.log 2>&1
+python3 $R/tools/encoder_mid.py > $O/encoder_mid.log 2>&1
 cut -c1-300 $O/bench_line.json
 ls $O
