@@ -1106,7 +1106,9 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     const int n_wg = std::max(1, std::min(std::min(c->n_cu, 256), (n_blocks + NWV - 1) / NWV));
     // the merge runs as the tail of the stream kernel while every query finds a workgroup of its own
     const bool fused = c->topks_fused && B <= n_wg;
-    if (c->topk_gemm && bf16 && B > 256 && n_blocks >= 64 && !c->topks_force_exact) {
+    // (the candidate lists of a call are addressed by 32-bit byte offsets: B x lists x 256 B < 4 GB - the
+    // Python layer calls in chunks of 16 384 queries = 1 GB at most)
+    if (c->topk_gemm && bf16 && B > 256 && n_blocks >= 64 && !c->topks_force_exact && B <= 60000) {
         // batches beyond the one-launch regime: GEMM-shaped, list-free (topk_gemm.h): group maxima ->
         // per-query threshold -> candidates -> float32 re-rank.  Two workgroups per CU; the splits fill
         // one round of them (at least 4: 32 row groups for the threshold; at least 8 tiles each).

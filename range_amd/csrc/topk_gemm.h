@@ -77,6 +77,35 @@ struct TopkGemmArgs {
     int32_t* exact_count;       // queries recomputed by brute force (optional)
 };
 
+// Pass B's append, for the lanes whose value reaches their threshold: (row, bits of S~) as ONE 8-byte
+// store to slot min(count, TG_CAP_L - 1) of the lane's own list, count + 1 - under an exec mask, skipped
+// as a whole when no lane of the wave has a hit for this accumulator register.  (Measured, ~200
+// candidates per query: pass B without hits 440 us; the rare branch and its per-group ballots +17; the
+// append's arithmetic +73 and its stores +73 as first written - four unconditional masked blocks per
+// group, two 4-byte stores per hit.)  The store is not counted by hipcc: every hand-counted vmcnt wait of the kernel only gets
+// stricter by younger operations (the counter retires in issue order).
+__device__ __forceinline__ void tg_append(float val, float th, uint32_t& count, uint32_t list_off, uint32_t row,
+                                          const void* cand) {
+    uint32_t t;
+    unsigned long long sv;
+    const unsigned long long pair = ((unsigned long long)__float_as_uint(val) << 32) | row;   // (row, bits of S~)
+    asm volatile(
+        "v_cmp_ge_f32 vcc, %[val], %[th]\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "s_cbranch_execz .Ltg_none_%=\n\t"          // (of a group's four values usually one reaches the threshold)
+        "v_min_u32 %[t], %[capm1], %[cnt]\n\t"
+        "v_add_u32 %[cnt], 1, %[cnt]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[off]\n\t"
+#ifndef RANGE_EXP_TG_NOSTORE     // (timing experiment: the append without its store)
+        "global_store_dwordx2 %[t], %[pair], %[cand]\n\t"
+#endif
+        ".Ltg_none_%=:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [sv] "=&s"(sv), [cnt] "+v"(count)
+        : [val] "v"(val), [th] "v"(th), [off] "v"(list_off), [pair] "v"(pair), [cand] "s"(cand), [capm1] "n"(TG_CAP_L - 1)
+        : "vcc", "memory");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
     for (int gi = 0; gi < TG_GQ; ++gi) {
         const int64_t q = q0 + gi * 16 + j;
         qok[gi] = q < a.B;
-        th[gi] = MODE == 1 ? a.theta[2 * (q < a.B ? q : a.B - 1)] : 0.f;
+        // (a lane whose query does not exist never reaches its threshold)
+        th[gi] = MODE == 1 ? (q < a.B ? a.theta[2 * q] : INFINITY) : 0.f;
         mx[gi][0] = mx[gi][1] = -INFINITY;
         nc[gi] = 0u;
     }
@@ -147,6 +177,11 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) prow[r] = (uint32_t)pi_row(4 * g + r);
     const uint32_t n_valid32 = (uint32_t)a.n_valid;
+    // byte offset of this lane's candidate list per group (the host keeps all lists below 4 GB)
+    uint32_t list_off[TG_GQ];
+#pragma unroll
+    for (int gi = 0; gi < TG_GQ; ++gi)
+        list_off[gi] = (uint32_t)(((((q0 + gi * 16 + j) * a.n_splits + split) * 4 + g) * TG_CAP_L) * sizeof(uint2));
 
     // Only the bank's last tile can hold pad rows (zero keys: similarity 0, which must neither raise a
     // group maximum nor become a candidate): it is kept out of the loop and handled behind it.
@@ -191,16 +226,14 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
         if (MODE == 1 && __builtin_amdgcn_ballot_w64(hit) != 0ull) {
 #pragma unroll
             for (int gi = 0; gi < TG_GQ; ++gi) {
-                if (qok[gi]) {
-                    uint2* list = a.cand + (((q0 + gi * 16 + j) * a.n_splits + split) * 4 + g) * TG_CAP_L;
+                const float m4 = fmaxf(fmaxf(acc[gi][0], acc[gi][1]), fmaxf(acc[gi][2], acc[gi][3]));
+                if (__builtin_amdgcn_ballot_w64(m4 >= th[gi]) == 0ull) continue;      // (wave-uniform)
+#ifndef RANGE_EXP_TG_NOAPPEND    // (timing experiment: the rare branch entered, nothing appended)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (acc[gi][r] >= th[gi]) {
-                            if (nc[gi] < (uint32_t)TG_CAP_L) list[nc[gi]] = make_uint2(row0 + prow[r], __float_as_uint(acc[gi][r]));
-                            ++nc[gi];
-                        }
-                    }
-                }
+                for (int r = 0; r < 4; ++r) tg_append(acc[gi][r], th[gi], nc[gi], list_off[gi], row0 + prow[r], a.cand);
+#else
+                asm volatile("s_nop 0" ::: "memory");
+#endif
             }
         }
     };
