@@ -40,7 +40,9 @@ for a, b in ev:
     b.record()
     if idle_ms:
         b.synchronize()
-        time.sleep(idle_ms * 1e-3)
+        t_end = time.perf_counter() + idle_ms * 1e-3          # (a spin, not a sleep: sub-millisecond gaps)
+        while time.perf_counter() < t_end:
+            pass
 torch.cuda.synchronize()
 ms = np.array([a.elapsed_time(b) for a, b in ev])
 cum = np.cumsum(ms)
