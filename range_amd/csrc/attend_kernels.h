@@ -34,6 +34,8 @@
 
 #include <type_traits>
 
+#include "host_plan.h"
+
 namespace range_hip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -113,9 +115,9 @@ struct SlabMap {
     int32_t n_qtiles;
     int32_t sk_cols;
 };
-__host__ __device__ __forceinline__ int64_t sk_start(int64_t w, int64_t U, int64_t G) { return (w * U) / G; }
-__host__ __device__ __forceinline__ int64_t sk_owner(int64_t u, int64_t U, int64_t G) { return ((u + 1) * G - 1) / U; }
-__host__ __device__ __forceinline__ int sk_col_begin(int c, int n_blocks, int n_cols) { return (int)(((int64_t)c * n_blocks) / n_cols); }
+using range_host::sk_col_begin;     // (host_plan.h: the partition arithmetic, also run under sanitizers on the CPU)
+using range_host::sk_owner;
+using range_host::sk_start;
 // parts of query q in column c (split-major: the one "column" holds all planes): float4 index of the
 // first, the stride between parts and their number
 __device__ __forceinline__ void slab_parts(const SlabMap& m, int64_t B, int64_t q, int c, int64_t& first4, int64_t& stride4, int& count) {

@@ -37,6 +37,23 @@ inline int choose_splits(int n_qtiles, int n_blocks, int n_cu, int wg_per_cu, in
     return best;
 }
 
+// Stream-K partition of pass 2 (attend_kernels.h: SlabMap / SegWalk; round 5): U units in order are cut
+// into G contiguous, near-equal ranges [start(w), start(w + 1)); owner(u) is the range a unit falls in.
+// The kernel walks by `start`, the reduction finds a query tile's parts by `owner`: both are these
+// functions (compiled for the device too: RANGE_HD), and tests/native/host_sanitize.cpp checks that they
+// agree for every unit.
+#ifndef RANGE_HD
+#if defined(__HIPCC__)
+#define RANGE_HD __host__ __device__ __forceinline__
+#else
+#define RANGE_HD inline
+#endif
+#endif
+RANGE_HD int64_t sk_start(int64_t w, int64_t U, int64_t G) { return (w * U) / G; }
+RANGE_HD int64_t sk_owner(int64_t u, int64_t U, int64_t G) { return ((u + 1) * G - 1) / U; }
+// first block of bank column c of n_cols (columns: contiguous, near-equal block ranges)
+RANGE_HD int sk_col_begin(int c, int n_blocks, int n_cols) { return (int)(((int64_t)c * n_blocks) / n_cols); }
+
 // Small-batch encoder: workgroups per 16-query tile = column parts S (a power of two, parts of
 // 64 .. 512 columns: the widths a kernel exists for) x K parts KP (ranges of at least 3 of the
 // first layer's slots).  Every workgroup gets its own CU (tiles * S * KP <= n_cu); K parts come

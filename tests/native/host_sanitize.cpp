@@ -64,6 +64,52 @@ static void test_plan_and_packing() {
     }
 }
 
+// the stream-K partition of pass 2: every unit in exactly one range, owner() the inverse of start(),
+// and the slab indices w + qtile of a walk unique (what SegWalk / slab_parts rely on)
+static void test_streamk_partition() {
+    const int64_t Gs[] = {1, 2, 7, 255, 256, 1024};
+    const int shapes[][2] = {{1, 4}, {1, 782}, {5, 63}, {79, 782}, {157, 782}, {157, 1024}, {3, 6250}, {1250, 97}};
+    for (int64_t G : Gs)
+        for (auto& sh : shapes) {
+            const int n_qtiles = sh[0], cb = sh[1];
+            const int64_t U = (int64_t)n_qtiles * cb;
+            CHECK(sk_start(0, U, G) == 0 && sk_start(G, U, G) == U);
+            for (int64_t w = 0; w < G; ++w) CHECK(sk_start(w, U, G) <= sk_start(w + 1, U, G));
+            // owner(u) = the w with start(w) <= u < start(w + 1)
+            const int64_t step = U > 5000 ? 37 : 1;
+            for (int64_t u = 0; u < U; u += step) {
+                const int64_t w = sk_owner(u, U, G);
+                CHECK(w >= 0 && w < G && sk_start(w, U, G) <= u && u < sk_start(w + 1, U, G));
+            }
+            for (int64_t w = 0; w < G; ++w) {      // (range boundaries exactly)
+                const int64_t a = sk_start(w, U, G), b = sk_start(w + 1, U, G);
+                if (a < b) CHECK(sk_owner(a, U, G) == w && sk_owner(b - 1, U, G) == w);
+            }
+            // the walk: segments (w, qtile) in order; slab index w + qtile strictly increases
+            int64_t last_slab = -1, covered = 0;
+            for (int64_t w = 0; w < G; ++w) {
+                int64_t u = sk_start(w, U, G);
+                const int64_t u_end = sk_start(w + 1, U, G);
+                while (u < u_end) {
+                    const int64_t qt = u / cb, bo = u - qt * cb;
+                    const int64_t n = std::min<int64_t>(u_end - u, cb - bo);
+                    CHECK(n > 0 && w + qt > last_slab && w + qt < G + n_qtiles);
+                    last_slab = w + qt;
+                    // the reduction's view of this query tile's parts contains this workgroup
+                    CHECK(sk_owner(qt * cb, U, G) <= w && w <= sk_owner((qt + 1) * cb - 1, U, G));
+                    covered += n;
+                    u += n;
+                }
+            }
+            CHECK(covered == U);
+        }
+    for (int n_blocks : {4, 63, 782, 6250})
+        for (int n_cols : {1, 2, 3, 7}) {
+            CHECK(sk_col_begin(0, n_blocks, n_cols) == 0 && sk_col_begin(n_cols, n_blocks, n_cols) == n_blocks);
+            for (int c = 0; c < n_cols; ++c) CHECK(sk_col_begin(c, n_blocks, n_cols) <= sk_col_begin(c + 1, n_blocks, n_cols));
+        }
+}
+
 static void test_choose_splits() {
     for (int qt : {1, 2, 16, 79, 157, 1563})
         for (int nb : {1, 3, 4, 64, 782, 3125, 6250})
@@ -171,6 +217,7 @@ int main() {
     test_padding_and_host_parts();
     test_plan_and_packing();
     test_choose_splits();
+    test_streamk_partition();
     test_encoder_split();
     test_copy_pool();
     std::puts("host_sanitize ok");

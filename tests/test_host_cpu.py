@@ -93,6 +93,20 @@ def test_bank_prep_matches_oracle_bitwise(tmp_path):
     assert sub.n_rows == 10 and np.array_equal(sub.keys, b.keys[10:20])
 
 
+def test_library_carries_this_checkouts_source_hash():
+    """build.sh embeds the SHA-256 of range_amd/csrc/* and include/*.h in the library: the file carries
+    it as a literal (read without loading), the loaded library returns the same, and both equal this
+    checkout's - what __graft_entry__.build() and the binding's refusal of a stale library rest on."""
+    import ctypes
+    from range_amd._srchash import library_stamp, source_sha256
+    here = source_sha256()
+    assert len(here) == 64 and library_stamp(_native.LIB_PATH) == here
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    lib.range_source_sha256.restype = ctypes.c_char_p
+    assert lib.range_source_sha256().decode() == here
+    assert library_stamp(__file__) is None                      # (a file without a stamp)
+
+
 def test_engine_requires_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
