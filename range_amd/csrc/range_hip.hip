@@ -1120,7 +1120,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         ga.n_valid = c->n_rows;
         ga.n_blocks = n_blocks;
         ga.n_qblocks = (int32_t)((B + TG_QBLOCK - 1) / TG_QBLOCK);
-        ga.n_splits = std::max(4, std::min(std::min(2 * c->n_cu / ga.n_qblocks, n_blocks / 8), 64));
+        ga.n_splits = std::max(4, std::min(std::min(TG_WG_PER_CU * c->n_cu / ga.n_qblocks, n_blocks / 8), 64));
         ga.k = k;
         ga.row_offset = c->row_offset;
         ga.oval = topk_val;
@@ -1155,14 +1155,14 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
             {
                 ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);
                 ga.tile_stride = std::max(1, std::min(c->tg_sample, n_blocks / ga.n_splits / 4));
-                hipLaunchKernelGGL(topk_gemm_kernel<0>, ggrid, dim3(256), TG_LDS_BYTES, s, ga);
+                hipLaunchKernelGGL(topk_gemm_kernel<0>, ggrid, dim3(TG_WAVES * 64), TG_LDS_BYTES, s, ga);
                 ga.tile_stride = 1;
                 hipLaunchKernelGGL(topk_gemm_threshold_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ga.gmax,
                                    ga.n_splits * 2, B, ehat32, TG_EPS_REL * c->key_norm_max, c->ws_tg_theta.p);
 #ifdef RANGE_EXP_TG_NOHIT       // timing experiment: pass B with a threshold nothing reaches (its MFMA + compare floor)
                 HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->ws_tg_theta.p, 0x7f800000, (size_t)B * 2, s));
 #endif
-                hipLaunchKernelGGL(topk_gemm_kernel<1>, ggrid, dim3(256), TG_LDS_BYTES, s, ga);
+                hipLaunchKernelGGL(topk_gemm_kernel<1>, ggrid, dim3(TG_WAVES * 64), TG_LDS_BYTES, s, ga);
             }
             ProfScope ps(c, RANGE_PROF_TOPK_MERGE, s);
             hipLaunchKernelGGL(topk_gemm_rerank_kernel, dim3((unsigned)B), dim3(256), 0, s, ga);

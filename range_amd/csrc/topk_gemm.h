@@ -43,7 +43,13 @@
 namespace range_hip {
 
 constexpr int TG_GQ = 4;                     // query groups (of 16) per wave
-constexpr int TG_QBLOCK = 4 * TG_GQ * 16;    // queries per workgroup
+#ifndef RANGE_TG_WAVES
+#define RANGE_TG_WAVES 4                     // waves per workgroup (4: two workgroups per CU; 8: one)
+#endif
+constexpr int TG_WAVES = RANGE_TG_WAVES;
+constexpr int TG_WG_PER_CU = 8 / TG_WAVES;
+constexpr int TG_QBLOCK = TG_WAVES * TG_GQ * 16;    // queries per workgroup
+constexpr int TG_DMA_PER_WAVE = 16 / TG_WAVES;      // 1 KB pieces of a phase's 2 x 8 KB each wave moves
 constexpr int TG_KT = 2;                     // key tiles per phase
 constexpr int TG_SLOTS = 3;
 constexpr int TG_LDS_BYTES = TG_SLOTS * TG_KT * TSB_TILE_BYTES;   // 48 KB
@@ -107,7 +113,7 @@ __device__ __forceinline__ void tg_append(float val, float th, uint32_t& count, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
+__global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,12 +169,14 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
     const char* kb = reinterpret_cast<const char*>(a.keys_bf16);
     const int last = b1 - 1;
     auto issue = [&](int p) __attribute__((always_inline)) {
-        const int tile = min(b0 + p * TG_KT + (wave >> 1), last);      // (past the split's end: re-read its last tile)
-        const char* src = kb + ((int64_t)t0 + (int64_t)tile * stride) * TSB_TILE_BYTES + (wave & 1) * 4096;
-        const uint32_t dst = lds0 + ((p % TG_SLOTS) * TG_KT + (wave >> 1)) * TSB_TILE_BYTES + (wave & 1) * 4096;
+        // (wave w moves pieces [w D, (w + 1) D) of the phase's 16, D = 16 / waves: a run inside one tile)
+        const int piece0 = wave * TG_DMA_PER_WAVE, tsel = piece0 >> 3, poff = (piece0 & 7) * 1024;
+        const int tile = min(b0 + p * TG_KT + tsel, last);      // (past the split's end: re-read its last tile)
+        const char* src = kb + ((int64_t)t0 + (int64_t)tile * stride) * TSB_TILE_BYTES + poff;
+        const uint32_t dst = lds0 + ((p % TG_SLOTS) * TG_KT + tsel) * TSB_TILE_BYTES + poff;
         dma_group_begin(dst);
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) dma_b128_q(src, (uint32_t)(lane << 4), i4);
+        for (int i4 = 0; i4 < TG_DMA_PER_WAVE; ++i4) dma_b128_q(src, (uint32_t)(lane << 4), i4);
     };
     issue(0);
     issue(1);
@@ -256,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void topk_gemm_kernel(TopkGemmArgs a) {
         // phase p has landed when at most the 4 operations of phase p + 1 are outstanding (own share;
         // the barrier makes it everybody's); every wave is then also done reading phase p - 1, whose
         // slot phase p + 2 takes
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        if (TG_DMA_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         issue(p + 2);
         if (p >= n_phase_main) continue;                     // (a last phase that held only the tail tile)
         const char* slot = smem + (p % TG_SLOTS) * TG_KT * TSB_TILE_BYTES + lane * 16;
