@@ -27,8 +27,8 @@ def engine(keep, bank):
 
 bad = 0
 for case in range(cases):
-    N = int(rng.choice([1, 3, 15, 16, 17, 31, 100, 257, 1000, 4099, 12345, 30000]))
-    B = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, 255, 256, 257, 700, 1500]))
+    N = int(rng.choice([1, 3, 15, 16, 17, 31, 100, 257, 1000, 1024, 4099, 12345, 30000, 60001]))
+    B = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, 255, 256, 257, 700, 1500, 3000]))
     bank = prepare_bank(*synth.make_bank(N, int(rng.integers(1 << 30))))
     ek, e0 = engine(True, bank), engine(False, bank)
     x = torch.from_numpy(synth.make_queries(B, seed=int(rng.integers(1 << 30)), lat_max=80.0)).cuda()
@@ -49,9 +49,10 @@ for case in range(cases):
     _, tv, ti = ek.scan_stats(e32, xq, tau, tau_geo, topk=k)
     _, tv0, ti0 = e0.scan_stats(e32, xq, tau, tau_geo, topk=k)
     ok &= torch.equal(ti, ti0) and torch.equal(tv, tv0)
-    if B <= 256:
-        sv, si = ek.topk_stream(e32, k)
-        ok &= torch.equal(si, ti) and torch.equal(sv, tv)
+    # the side channel's own kernels: the streaming scan (up to 256 queries) / the GEMM-shaped path
+    # (topk_gemm.h, beyond) must return the same values and rows
+    sv, si = ek.topk_stream(e32, k)
+    ok &= torch.equal(si, ti) and torch.equal(sv, tv)
     m = _native.MODEL_RANGE_PLUS if tau_geo > 0 else _native.MODEL_RANGE
     ok &= torch.equal(ek.forward(x, m, beta), e0.forward(x, m, beta))
     print(f"case {case:3d}: N={N:6d} B={B:5d} tau={tau} geo={tau_geo} beta={beta} k={k:2d} {'ok' if ok else 'MISMATCH'}",
