@@ -92,7 +92,6 @@ struct EncArgs {
     uint32_t* sync;
     uint32_t* err;              // host-mapped word (or null): set when a bounded in-kernel wait gave up
     int32_t debug_giveup;       // test hook: every in-launch wait behaves as if it had expired
-    int32_t skip_fill;          // encoder_tile_kernel, a workgroup's 2nd.. part of a phase: its input is in LDS already
     const double* wp[ENC_MAX_LAYERS];     // packed weights, pair-fragment order (see gemm_kpairs)
     const double* bias[ENC_MAX_LAYERS];
 };
@@ -255,7 +254,8 @@ __device__ __forceinline__ void store_act(double* lds, const double* bias, doubl
 // columns has few n-tiles to compute but the whole feature set to generate).
 template <int NT, int NW, int QT, int MODE = 0, int NWT = NW>
 __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char* smem, int part = 0,
-                                             int kpart = 0) {
+                                             int kpart = 0, bool skip_fill = false) {
+    // (skip_fill: encoder_tile_kernel, a workgroup's 2nd.. part of a phase - its input is in LDS already)
     constexpr int NTW = 4 * NT / NW;   // hidden n-tiles per wave
     constexpr int EW = 16 / NW;        // output n-tiles per wave
     constexpr int PF = (MODE != 0 && NTW <= 2) ? ENC_PF_SMALL : ENC_PF;   // depth of the weight stream's register ring
@@ -444,7 +444,7 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         return;
     }
     const int l0 = MODE == 2 ? a.rest_from : 0;   // first layer whose activation is already in LDS
-    if ((MODE == 3 || MODE == 4) && a.skip_fill) {
+    if ((MODE == 3 || MODE == 4) && skip_fill) {
         // (the previous part of this phase left the tile's input in LDS)
     } else if ((MODE == 2 && l0 == 1) || MODE == 4) {
         // the activated second layer of this tile, written by the MODE 3 workgroups
@@ -813,21 +813,15 @@ __global__ __launch_bounds__(ENC_PART_WAVES * 64, 1) void encoder_tile_kernel(En
     // (parts of 64 columns with K split four ways where a tile has >= H / 64 workgroups; wider parts -
     // 128 or 256 columns, one n-tile per wave over the whole K - where it has fewer: the host chooses)
     for (int part = b; part < a.n_parts2; part += K) {
-        EncArgs a3 = a;
-        a3.skip_fill = part != b;
-        if (a.part2_cols == 64) encoder_body<1, 4, 1, 3>(a3, q0, smem, part);
-        else if (a.part2_cols == 128) encoder_body<2, 8, 1, 3>(a3, q0, smem, part);
-        else encoder_body<4, 16, 1, 3>(a3, q0, smem, part);
+        if (a.part2_cols == 64) encoder_body<1, 4, 1, 3>(a, q0, smem, part, 0, part != b);
+        else if (a.part2_cols == 128) encoder_body<2, 8, 1, 3>(a, q0, smem, part, 0, part != b);
+        else encoder_body<4, 16, 1, 3>(a, q0, smem, part, 0, part != b);
     }
     ENC_STAMP(5);
     // ---- last layer on workgroups 0..3
     ENC_HANDOFF(sync + 128, K, K, true);
     ENC_STAMP(6);
-    for (int part = b; part < 4; part += K) {
-        EncArgs a4 = a;
-        a4.skip_fill = part != b;
-        encoder_body<4, 4, 1, 4>(a4, q0, smem, part);
-    }
+    for (int part = b; part < 4; part += K) encoder_body<4, 4, 1, 4>(a, q0, smem, part, 0, part != b);
     ENC_STAMP(7);
     // ---- norm on workgroup 0: a wave per query
     ENC_HANDOFF(sync + 192, K, 1, b == 0);

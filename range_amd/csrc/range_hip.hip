@@ -115,6 +115,7 @@ struct range_ctx {
     uint32_t* d_async_err = nullptr;
     bool enc_fused = true;          // RANGE_ENC_FUSED=0: up to 16 queries take the separate small-batch kernels
     bool enc_fused_mid = true;      // RANGE_ENC_FUSED_MID=0: 513 .. 2 048 queries as three launches (A/B)
+    int enc_fused_mid_min_wg = 2;   // RANGE_ENC_FUSED_MID_MIN_WG=n: ... one launch while a tile gets >= n workgroups (tuning)
     int last_qtiles = 0, last_splits = 0;
     bool p2_streamk = true;         // RANGE_P2_STREAMK=0: pass 2 as one workgroup per (bank split, query tile) (A/B)
     int p2_col_rows = 16384;        // RANGE_P2_COL_ROWS=n: largest bank column of the stream-K walk (rows; tuning)
@@ -192,18 +193,18 @@ int launch_encoder_split(range_ctx* c, EncArgs a, int S, int KP, hipStream_t s) 
     // up to 32 tiles (512 queries): all phases in ONE launch (encoder_tile_kernel), every tile on its own
     // workgroups, where a tile's first-layer workgroups are enough to carry its later phases (H / 64 of
     // them the second layer, 4 the last)
-    // ... and, round 5, more tiles while a tile still gets >= 5 workgroups (up to 51 tiles = 816 queries):
-    // those take the parts of the later phases in turns - 513 queries 100 us instead of 114 as three
-    // launches, 625 queries 104 instead of 116.  Beyond (2-3 workgroups per tile: a rank's 1 250 queries
-    // of an 8-GPU batch, a large batch's last partial round) the one launch measured SLOWER - 1 250
-    // queries 155-159 us against 132, 2 048 queries 190 against 157 (tools/encoder_mid.py) - and stays
-    // three launches.  Phase stamps of tile 0 at 1 250 queries (us): first layer 51, wait 12, activation
-    // 4, second layer 22 (6 of them filling LDS), wait 10, last layer 41 (two parts of 64 outputs, one
-    // after the other: each streams 256 KB of weights + 64 KB of input into ONE CU, ~20 us), norm 3: the
-    // later phases are bound by what a single CU can pull, and the separate launches spread them over
-    // more CUs (RANGE_ENC_FUSED_MID=0: three launches everywhere, A/B).
+    // ... and, round 5, up to 128 tiles (2 048 queries: a rank's share of an 8-GPU batch, the last partial
+    // round of a large batch): the 2-7 workgroups a tile then gets take the parts of the later phases in
+    // turns (second-layer parts of 128 / 256 columns where a tile has < 8 / < 4 workgroups).  One launch
+    // against three (tools/encoder_mid.py, steady state): 513 queries 83 us / 114, 800: 93 / 118, 1 024:
+    // 102 / 122, 1 250: 128 / 132, 1 536 - 2 048: 155-156 / 157.  (The first version of this looked SLOWER
+    // beyond 816 queries and cost the <= 512-query path 15 us: per-part copies of the argument struct inside
+    // the phase loops had put 456 B of it into scratch memory - found through the latency log, now refused by
+    // tests/test_host_cpu.py.)  Phase stamps of a tile at 1 250 queries (us): first layer 49, wait 11,
+    // activation 4, second layer 21 (6 of them filling LDS), wait 10, last layer 16 (two parts of 64 outputs on
+    // the tile's first workgroup), norm 3.  RANGE_ENC_FUSED_MID=0: three launches (A/B).
     const bool few_tiles = tiles <= 32 && S * KP >= std::max(std::max(a.H / 64, 4), (16 * a.H + 1023) / 1024);
-    const bool mid_tiles = tiles > 32 && tiles <= 128 && S * KP >= 5 && c->enc_fused_mid;
+    const bool mid_tiles = tiles > 32 && tiles <= 128 && S * KP >= c->enc_fused_mid_min_wg && c->enc_fused_mid;
     if ((few_tiles || mid_tiles) && a.n_layers == 2 && c->enc_fused && a.H % 64 == 0 && a.H <= 512 && tiles * S * KP <= c->n_cu) {
         if (c->ws_h2.ensure((size_t)tiles * 16 * a.H) != hipSuccess || c->ws_h1a.ensure((size_t)tiles * 16 * a.H) != hipSuccess ||
             c->ws_e3.ensure((size_t)tiles * 16 * ENC_EMBED + 64) != hipSuccess || c->ws_enc_sync.ensure(128 * 256) != hipSuccess)
@@ -542,6 +543,7 @@ int range_create(int device, range_ctx** out) {
     if (const char* e = std::getenv("RANGE_ENC_SPLIT3")) c->enc_split3 = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_FUSED")) c->enc_fused = e[0] != '0';
     if (const char* e = std::getenv("RANGE_ENC_FUSED_MID")) c->enc_fused_mid = e[0] != '0';
+    if (const char* e = std::getenv("RANGE_ENC_FUSED_MID_MIN_WG")) c->enc_fused_mid_min_wg = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RANGE_ENC_TAIL")) c->enc_tail_split = e[0] != '0';
     if (const char* e = std::getenv("RANGE_TOPKS_GROUPS")) c->topks_groups = std::atoi(e);
     if (const char* e = std::getenv("RANGE_TOPKS_FORCE_EXACT")) c->topks_force_exact = e[0] == '1';

@@ -214,6 +214,16 @@ def test_no_foreign_m0_writes(tmp_path):
                     last_mfma = max(i for i, b in enumerate(body) if b.startswith("v_mfma"))
                     assert idx > last_mfma, f"{name}: accumulator of an asm MFMA read inside the loop: {l}"
     assert n_small == 4
+    # fifth check: the persistent encoder launch and the batch top-k's GEMM passes must not use scratch
+    # memory (round 5: per-part copies of the argument struct inside encoder_tile_kernel's loops put 456 B
+    # of it on the stack - the small-batch encoder went from 58 to 74 us before anyone looked)
+    n_noscratch = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if "encoder_tile_kernel" in name or "topk_gemm_kernel" in name or "attend_stored_kernel" in name:
+            n_noscratch += 1
+            assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", k), f"{name} uses scratch memory"
+    assert n_noscratch >= 8
 
 
 def test_bankfile_roundtrip_and_shards(tmp_path):
