@@ -97,6 +97,8 @@ struct range_ctx {
     int tg_sample = TG_SAMPLE;               // RANGE_TG_SAMPLE=n: pass A of the batch top-k looks at every n-th tile (tuning)
     bool topk_gemm = true;                   // RANGE_TOPK_GEMM=0: batches beyond 256 queries through the streaming scan too (A/B)
     DevBuf<float> ws_tg_gmax, ws_tg_theta;   // topk_gemm.h: group maxima (n_splits * 2, B, 4), thresholds (B)
+    DevBuf<uint32_t> ws_tg_qfrag;            // ... the call's queries as fp16 fragments (512 B per query)
+    DevBuf<float> ws_tg_qscale;              // ... and their scales
     DevBuf<uint32_t> ws_tg_cnt, ws_tg_ovf;
     DevBuf<uint2> ws_tg_cand;                  // candidate lists: lengths (B, lists), rows (B, lists, TG_CAP_L); overflow flags (B)
     int p2_splits_forced = 0;                // RANGE_P2_SPLITS=n: pass 2 with n bank splits (tuning)
@@ -104,6 +106,8 @@ struct range_ctx {
     DevBuf<float> ws_small_o, ws_small_z;    // attend_small_kernel: per-workgroup partial products / weight sums
     DevBuf<uint32_t> ws_read_sink;           // range_stream_read_timed: one word per workgroup
     DevBuf<uint32_t> d_keys_bf16;            // bf16 copy of the keys in MFMA fragment order (8 KB per 16 rows)
+    DevBuf<uint32_t> d_keys_f16;             // fp16 copy x tg_key_scale, same order: the batch top-k's (built on its first call)
+    float tg_key_scale = 0.f;                // 0: not built for the current keys
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
     DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
@@ -696,6 +700,7 @@ int range_set_sh_table(range_ctx* c, int32_t L, const double* front, const doubl
 // streams) and the largest row norm, computed on the device.  `keys` may be a host or a device
 // pointer (hipMemcpyDefault).
 static int upload_keys(range_ctx* c, const float* keys, int64_t n_rows, int64_t n_pad) {
+    c->tg_key_scale = 0.f;       // (the batch top-k rebuilds its fp16 copy for the new keys)
     HIP_TRY(c->d_keys.ensure((size_t)n_pad * KEY_DIM));
     if (n_pad > n_rows)
         HIP_TRY(hipMemset(c->d_keys.p + (size_t)n_rows * KEY_DIM, 0, (size_t)(n_pad - n_rows) * KEY_DIM * 4));
@@ -1115,7 +1120,20 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         // per-query threshold -> candidates -> float32 re-rank.  Two workgroups per CU; the splits fill
         // one round of them (at least 4: 32 row groups for the threshold; at least 8 tiles each).
         TopkGemmArgs ga{};
-        ga.keys_bf16 = c->d_keys_bf16.p;
+        if (c->tg_key_scale == 0.f) {
+            // the fp16 copy of the keys, scaled so that the largest row norm lies in [2^13, 2^14)
+            int e2 = 0;
+            (void)std::frexp((double)c->key_norm_max, &e2);            // key_norm_max < 2^e2
+            const float ks = (float)std::ldexp(1.0, 14 - e2);
+            const int64_t n_tiles = c->n_pad / BLK;
+            HIP_TRY(c->d_keys_f16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
+            const int64_t threads = n_tiles * 8 * 64;
+            hipLaunchKernelGGL(keyfrag_f16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, c->d_keys.p,
+                               c->n_pad, n_tiles, ks, reinterpret_cast<ts_u32x4*>(c->d_keys_f16.p));
+            HIP_TRY(hipGetLastError());
+            c->tg_key_scale = ks;
+        }
+        ga.keys_f16 = c->d_keys_f16.p;
         ga.keys = c->d_keys.p;
         ga.ehat = ehat32;
         ga.B = B;
@@ -1138,6 +1156,10 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         HIP_TRY(c->ws_tg_cand.ensure((size_t)B * ga.n_splits * 4 * TG_CAP_L));
         HIP_TRY(c->ws_tg_ovf.ensure((size_t)B));
         ga.ovf = c->ws_tg_ovf.p;
+        const int64_t n_qgroups = (B + 15) / 16;
+        HIP_TRY(c->ws_tg_qfrag.ensure((size_t)n_qgroups * 8 * 64 * 4));
+        HIP_TRY(c->ws_tg_qscale.ensure((size_t)B));
+        ga.qfrag = c->ws_tg_qfrag.p;
         ga.gmax = c->ws_tg_gmax.p;
         ga.theta = c->ws_tg_theta.p;
         ga.cnt = c->ws_tg_cnt.p;
@@ -1156,11 +1178,13 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
         for (int rep = 0; rep < std::max(1, repeats); ++rep) {
             {
                 ProfScope ps(c, RANGE_PROF_TOPK_STREAM, s);
+                hipLaunchKernelGGL(qfrag_f16_kernel, dim3((unsigned)n_qgroups), dim3(256), 0, s, ehat32, B,
+                                   reinterpret_cast<ts_u32x4*>(c->ws_tg_qfrag.p), c->ws_tg_qscale.p);
                 ga.tile_stride = std::max(1, std::min(c->tg_sample, n_blocks / ga.n_splits / 4));
                 hipLaunchKernelGGL(topk_gemm_kernel<0>, ggrid, dim3(TG_WAVES * 64), TG_LDS_BYTES, s, ga);
                 ga.tile_stride = 1;
                 hipLaunchKernelGGL(topk_gemm_threshold_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ga.gmax,
-                                   ga.n_splits * 2, B, ehat32, TG_EPS_REL * c->key_norm_max, c->ws_tg_theta.p);
+                                   ga.n_splits * 2, B, ehat32, TG_EPS_REL * c->key_norm_max, c->tg_key_scale, c->ws_tg_qscale.p, c->ws_tg_theta.p);
 #ifdef RANGE_EXP_TG_NOHIT       // timing experiment: pass B with a threshold nothing reaches (its MFMA + compare floor)
                 HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->ws_tg_theta.p, 0x7f800000, (size_t)B * 2, s));
 #endif

@@ -6,8 +6,8 @@
 // Cache, bound by list maintenance and pass seams (3.9 ms, round 4) - while the arithmetic,
 // 2 x 256 x 10^9 FLOP, is 0.2 ms of bf16 MFMA.  Here the scan is GEMM-shaped and list-free:
 //
-//   pass A  topk_gemm_kernel<0>  approximate similarities S~ = K~ Q~^T (bf16 operands, f32
-//           accumulation: v_mfma_f32_16x16x32_bf16) of a SAMPLE of the bank - every TG_SAMPLE-th
+//   pass A  topk_gemm_kernel<0>  approximate similarities S~ = K~ Q~^T (fp16 operands scaled by powers
+//           of two, f32 accumulation: v_mfma_f32_16x16x32_f16) of a SAMPLE of the bank - every TG_SAMPLE-th
 //           16-row tile - of which only the MAXIMUM per (query, row group) is kept: one v_max per
 //           value.  Row groups = bank splits x 2 tile parities x 4 accumulator lane groups:
 //           disjoint row sets, at least 16 of them.
@@ -25,6 +25,16 @@
 //           their FLOAT32 similarity by the fmaf chain every float32 kernel of this library computes
 //           (topk_exact_dot) and are ranked by (value, lower row first): values and indices are
 //           those of the float32 scan, bit for bit.
+//
+// Operands: the keys as fp16 in the MFMA fragment order of the streaming scan's bf16 copy
+// (keyfrag_f16_kernel: built on the first call that needs it, 512 B per row), scaled by the power of two
+// that puts the largest key norm in [2^13, 2^14); a query scaled by the power of two that puts its
+// largest element there.  Both scalings are exact, keep every element that matters in fp16's normal
+// range (an element that falls below 2^-14 after scaling is below 2^-27 of the operand's largest: its
+// loss is 2^-23 relative), and make S~ a per-query multiple of the similarity - thresholds, candidates'
+// values and eps of a query live in that query's scale.  fp16 instead of bf16 (same MFMA rate): eps is
+// a quarter, and both the appends of pass B and the re-rank's row gathers scale with the width of
+// the 2-eps band (bf16: 0.84 ms under the profiler for 10^4 x 10^5; fp16: see DESIGN.md section 3.5).
 //
 // Exactness: |S~ - S| <= eps = TG_EPS_REL |q| max|k| for every pair.  At least 16 rows have
 // S~ >= v16, hence S >= v16 - eps: the 16th best exact value is >= v16 - eps and every member of the
@@ -57,14 +67,90 @@ constexpr int TG_SAMPLE = 4;                 // pass A looks at every 4th tile
 constexpr int TG_CAP = 1024;                 // candidates of a query the re-rank takes in (all lists together)
 constexpr int TG_CAP_L = 32;                 // slots per (query, bank split, lane group) list
 constexpr int TG_CAP_X = 256;                // candidates whose float32 similarity the re-rank evaluates
-// eps / (|q| |k|): key rounding 2^-9 + query rounding 2^-9 + their product 2^-18 = 0.0039101, bf16
-// MFMA accumulation (256 terms, f32) 1.6e-5, the float32 chain's own rounding 1.5e-5: 0.0039411
-constexpr float TG_EPS_REL = 0.0040f;
+// eps / (|q| |k|): key rounding 2^-11 + query rounding 2^-11 + their product 2^-22 = 0.00097680, elements
+// lost below fp16's normal range 2 x 2^-23, MFMA accumulation (256 terms, f32) 1.6e-5, the float32
+// chain's own rounding 1.5e-5: 0.0010080
+constexpr float TG_EPS_REL = 0.00105f;
+typedef _Float16 ts_f16x8 __attribute__((ext_vector_type(8)));
+
+// two floats -> packed fp16, round to nearest even: gfx950's v_cvt_pk_f16_f32 (bitwise the (_Float16) cast
+// on 2^24 pairs incl. exact ties and subnormal results: tools/micro/cvt_pk_f16_rne.hip)
+__device__ __forceinline__ uint32_t tg_cvt_pk_f16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the power of two that puts a positive float's value in [2^13, 2^14) (1 for zero / denormal input)
+__device__ __forceinline__ float tg_scale_to_2p13(float mx) {
+    const uint32_t E = (__float_as_uint(mx) >> 23) & 0xFFu;
+    if (E == 0u) return 1.0f;
+    const uint32_t f = 267u - E;                  // 2^(13 - (E - 127))
+    return __uint_as_float((f > 254u ? 254u : f) << 23);
+}
+
+// queries (B x 256 f32) -> fp16 B-operand fragments of v_mfma_f32_16x16x32_f16, each query scaled by the power
+// of two that puts its largest element in [2^13, 2^14) (qscale[q]; rows past B: copies of the last query):
+// group grp of 16 queries, chunk c, lane (j, kg): Q[16 grp + j][32 c + 8 kg + 0..7].  One workgroup per group.
+__global__ __launch_bounds__(256) void qfrag_f16_kernel(const float* __restrict__ ehat, int64_t B,
+                                                        ts_u32x4* __restrict__ out, float* __restrict__ qscale) {
+    __shared__ float sh_mx[16][17];
+    const int t = threadIdx.x, j = t & 15, part = t >> 4;            // 16 parts of 16 elements per query
+    const int64_t grp = blockIdx.x;
+    const int64_t q = grp * 16 + j < B ? grp * 16 + j : B - 1;
+    const f32x4* row = reinterpret_cast<const f32x4*>(ehat + q * KEY_DIM + 16 * part);
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v = row[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    sh_mx[j][part] = m;
+    __syncthreads();
+    if (part == 0) {
+        float mm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, sh_mx[j][i]);
+        const float sc = tg_scale_to_2p13(mm);
+        sh_mx[j][16] = sc;
+        if (grp * 16 + j < B) qscale[grp * 16 + j] = sc;
+    }
+    __syncthreads();
+    for (int item = t; item < 8 * 64; item += 256) {                  // (chunk, lane) of this group
+        const int c = item >> 6, ln = item & 63, jj = ln & 15, kg = ln >> 4;
+        const int64_t qq = grp * 16 + jj < B ? grp * 16 + jj : B - 1;
+        const float sc = sh_mx[jj][16];
+        const f32x4* src = reinterpret_cast<const f32x4*>(ehat + qq * KEY_DIM + 32 * c + 8 * kg);
+        const f32x4 v0 = src[0] * sc, v1 = src[1] * sc;
+        ts_u32x4 o;
+        o[0] = tg_cvt_pk_f16(v0.x, v0.y); o[1] = tg_cvt_pk_f16(v0.z, v0.w);
+        o[2] = tg_cvt_pk_f16(v1.x, v1.y); o[3] = tg_cvt_pk_f16(v1.z, v1.w);
+        out[(grp * 8 + c) * 64 + ln] = o;
+    }
+}
+
+// keys (n_alloc rows x 256 f32) x scale -> fp16 A-operand fragments, the layout of keyfrag_kernel
+__global__ __launch_bounds__(256) void keyfrag_f16_kernel(const float* __restrict__ keys, int64_t n_alloc,
+                                                          int64_t n_tiles, float scale, ts_u32x4* __restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_tiles * 8 * 64) return;
+    const int lane = (int)(id & 63), c = (int)((id >> 6) & 7);
+    const int64_t t = id >> 9;
+    const int64_t row = t * 16 + pi_row(lane & 15);
+    ts_u32x4 o = {0u, 0u, 0u, 0u};
+    if (row < n_alloc) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(keys + row * KEY_DIM + 32 * c + 8 * (lane >> 4));
+        const f32x4 a = src[0] * scale, b = src[1] * scale;
+        o[0] = tg_cvt_pk_f16(a.x, a.y); o[1] = tg_cvt_pk_f16(a.z, a.w);
+        o[2] = tg_cvt_pk_f16(b.x, b.y); o[3] = tg_cvt_pk_f16(b.z, b.w);
+    }
+    out[id] = o;
+}
 
 struct TopkGemmArgs {
-    const void* keys_bf16;      // (n_tiles, 8 chunks, 64 lanes, 8) bf16 (keyfrag_kernel)
+    const void* keys_f16;       // (n_tiles, 8 chunks, 64 lanes, 8) fp16 x key_scale (keyfrag_f16_kernel)
     const float* keys;          // (n_pad, 256) f32 (rerank)
     const float* ehat;          // (B, 256)
+    const void* qfrag;          // (ceil(B/16), 8 chunks, 64 lanes, 8) fp16: the queries as B-operand fragments, scaled (qfrag_f16_kernel)
     int64_t B;
     int64_t n_valid;
     int32_t n_blocks;
@@ -128,19 +214,19 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
     const int n_phase = (b1 - b0 + TG_KT - 1) / TG_KT;
     const int64_t q0 = (int64_t)qb * TG_QBLOCK + wave * (TG_GQ * 16);
 
-    // B operand: lane (n = query j, kg = g) holds Q[j][32 c + 8 g + 0..7] of chunk c, one bf16 plane
+    // B operand: lane (n = query j, kg = g) holds Q[j][32 c + 8 g + 0..7] of chunk c as fp16 - converted and
+    // scaled once per call by qfrag_f16_kernel (every workgroup of both passes converting its 256 queries
+    // itself cost pass A 20 % of its time): 16 bytes per lane and chunk, coalesced
     ts_u32x4 qf[TG_GQ][8];
+    {
+        const ts_u32x4* qsrc = reinterpret_cast<const ts_u32x4*>(a.qfrag);
+        const int64_t n_groups = (a.B + 15) / 16;
 #pragma unroll
-    for (int gi = 0; gi < TG_GQ; ++gi) {
-        const int64_t q = q0 + gi * 16 + j;
-        const f32x4* rowp = reinterpret_cast<const f32x4*>(a.ehat + (q < a.B ? q : a.B - 1) * KEY_DIM);
+        for (int gi = 0; gi < TG_GQ; ++gi) {
+            int64_t grp = (q0 >> 4) + gi;
+            grp = grp < n_groups ? grp : n_groups - 1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 v0 = rowp[8 * c + 2 * g], v1 = rowp[8 * c + 2 * g + 1];
-            qf[gi][c][0] = ts_cvt_pk_bf16(v0.x, v0.y);
-            qf[gi][c][1] = ts_cvt_pk_bf16(v0.z, v0.w);
-            qf[gi][c][2] = ts_cvt_pk_bf16(v1.x, v1.y);
-            qf[gi][c][3] = ts_cvt_pk_bf16(v1.z, v1.w);
+            for (int c = 0; c < 8; ++c) qf[gi][c] = qsrc[(grp * 8 + c) * 64 + lane];
         }
     }
     float th[TG_GQ];            // pass B: this lane's query's threshold per group
@@ -166,7 +252,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
 
     // ring: phase p = tiles b0 + TG_KT p .. ; wave w moves half (w & 1) of tile (w >> 1): 4 x 1 KB
     const uint32_t lds0 = (uint32_t)(uintptr_t)RANGE_LPTR(smem);
-    const char* kb = reinterpret_cast<const char*>(a.keys_bf16);
+    const char* kb = reinterpret_cast<const char*>(a.keys_f16);
     const int last = b1 - 1;
     auto issue = [&](int p) __attribute__((always_inline)) {
         // (wave w moves pieces [w D, (w + 1) D) of the phase's 16, D = 16 / waves: a run inside one tile)
@@ -207,8 +293,8 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ts_bf16x8, kf[c]),
-                                                             __builtin_bit_cast(ts_bf16x8, qf[gi][c]), c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ts_f16x8, kf[c]),
+                                                            __builtin_bit_cast(ts_f16x8, qf[gi][c]), c0, 0, 0, 0);
             acc[gi] = c0;
         }
     };
@@ -306,10 +392,12 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
 }
 
 // theta[q] = {(the 16th largest of the query's n_parts x 4 group maxima) - 2 eps, 2 eps}, eps = eps_kmax |q|
+// in the query's scale of S~
 // (with 1e-4 of slack for the rounding of the norm and of the subtraction);
 // -inf when fewer than 16 groups saw a row (every row is then a candidate).  One wave per query.
 __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* __restrict__ gmax, int n_parts, int64_t B,
                                                                   const float* __restrict__ ehat, float eps_kmax,
+                                                                  float key_scale, const float* __restrict__ qscale,
                                                                   float* __restrict__ theta) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -328,8 +416,9 @@ __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* _
     for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
     if (lane == 0) {
         const float t16 = L.k[MAX_TOPK - 1] ? topk_key_val(L.k[MAX_TOPK - 1]) : -INFINITY;
-        // (the margin carries 1e-4 of slack: the rounding of this subtraction and of the norm)
-        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f;
+        // the query's scale of S~ (topk_gemm_kernel: the keys' and this query's powers of two); the margin
+        // carries 1e-4 of slack for the rounding of this subtraction and of the norm
+        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f * (key_scale * qscale[q]);
         theta[2 * q] = t16 > -INFINITY ? t16 - eps2 : -INFINITY;
         theta[2 * q + 1] = eps2;
     }
