@@ -805,9 +805,9 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
         del keys_dev
     # the north star's own sentence: the top-k similarity scan over range_db_large for the 10 000-query
     # batch (``model.topk``).  Beyond 256 queries the scan is GEMM-shaped (range_amd/csrc/topk_gemm.h,
-    # round 5): bf16 MFMA products of every (query, key) pair - a sampled pass for per-query thresholds,
+    # round 5): fp16 MFMA products (operands scaled by powers of two) of every (query, key) pair - a sampled pass for per-query thresholds,
     # a full pass that appends the candidates, a float32 re-rank; values and indices are those of the
-    # float32 scan bit for bit.  Its bound is the bf16 MFMA peak, not HBM: the 51 MB of bf16 keys sit in
+    # float32 scan bit for bit.  Its bound is the 16-bit MFMA peak, not HBM: the 51 MB of fp16 keys sit in
     # the Infinity Cache.  ``frac`` = the ALGORITHMIC products 2 x 256 x B x N / time / 2.5 PFLOP/s;
     # ``executed_flop`` adds the sampled pass (1 / TG_SAMPLE of a pass).
     nq = 10_000
@@ -828,10 +828,10 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
     flop = 2.0 * 256 * nq * N
     out.append({"kernel": "topk_gemm_kernel<0> (sampled group maxima) + threshold + topk_gemm_kernel<1> (candidates) + "
                           "topk_gemm_rerank_kernel (float32 re-rank): range_amd/csrc/topk_gemm.h",
-                "keys": "bf16", "bank_rows": N, "resident": "infinity_cache", "queries": nq,
+                "keys": "fp16", "bank_rows": N, "resident": "infinity_cache", "queries": nq,
                 "us_per_call": us, "us_source": "20 calls between one HIP event pair, after 20 untimed ones",
                 "us_scan_kernels": scan_us, "us_rerank": rerank_us,
-                "bound": "mfma bf16", "algorithmic_flop": flop, "executed_flop": flop * 1.25,
+                "bound": "mfma fp16", "algorithmic_flop": flop, "executed_flop": flop * 1.25,
                 "achieved_tflops": flop / (us * 1e-6) / 1e12, "peak_tflops": 2500.0,
                 "frac": flop / (us * 1e-6) / 1e12 / 2500.0,
                 "queries_per_s": nq / (us * 1e-6), "product_path": True,

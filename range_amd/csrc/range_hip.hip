@@ -1124,7 +1124,7 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
             // the fp16 copy of the keys, scaled so that the largest row norm lies in [2^13, 2^14)
             int e2 = 0;
             (void)std::frexp((double)c->key_norm_max, &e2);            // key_norm_max < 2^e2
-            const float ks = (float)std::ldexp(1.0, 14 - e2);
+            const float ks = (float)std::ldexp(1.0, std::max(-100, std::min(100, 14 - e2)));   // (finite for any norm)
             const int64_t n_tiles = c->n_pad / BLK;
             HIP_TRY(c->d_keys_f16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
             const int64_t threads = n_tiles * 8 * 64;

@@ -4,7 +4,7 @@
 // over the keys, every value pushed through per-lane candidate lists.  At BASELINE's batch (10 000
 // queries against range_db_large) that is 313 passes re-streaming a bank that sits in the Infinity
 // Cache, bound by list maintenance and pass seams (3.9 ms, round 4) - while the arithmetic,
-// 2 x 256 x 10^9 FLOP, is 0.2 ms of bf16 MFMA.  Here the scan is GEMM-shaped and list-free:
+// 2 x 256 x 10^9 FLOP, is 0.2 ms of 16-bit MFMA.  Here the scan is GEMM-shaped and list-free:
 //
 //   pass A  topk_gemm_kernel<0>  approximate similarities S~ = K~ Q~^T (fp16 operands scaled by powers
 //           of two, f32 accumulation: v_mfma_f32_16x16x32_f16) of a SAMPLE of the bank - every TG_SAMPLE-th
@@ -34,7 +34,8 @@
 // loss is 2^-23 relative), and make S~ a per-query multiple of the similarity - thresholds, candidates'
 // values and eps of a query live in that query's scale.  fp16 instead of bf16 (same MFMA rate): eps is
 // a quarter, and both the appends of pass B and the re-rank's row gathers scale with the width of
-// the 2-eps band (bf16: 0.84 ms under the profiler for 10^4 x 10^5; fp16: see DESIGN.md section 3.5).
+// the 2-eps band (10^4 x 10^5: bf16 operands 0.84 ms, fp16 0.77 ms).  The queries'
+// fragments are written once per call (qfrag_f16_kernel, 5 us), not by every workgroup of both passes.
 //
 // Exactness: |S~ - S| <= eps = TG_EPS_REL |q| max|k| for every pair.  At least 16 rows have
 // S~ >= v16, hence S >= v16 - eps: the 16th best exact value is >= v16 - eps and every member of the
@@ -42,7 +43,7 @@
 // overflow (a bank of near-duplicates; a sample that missed the query's neighbourhood) is recomputed
 // by brute force (topk_gemm_brute_kernel): slower, never wrong.
 //
-// Decomposition: workgroup = 4 waves = 256 queries (wave w: 4 groups of 16 queries, their bf16
+// Decomposition: workgroup = 4 waves = 256 queries (wave w: 4 groups of 16 queries, their fp16
 // fragments in 128 registers for the whole kernel) x one bank split; key tiles (16 rows = 8 KB in
 // the fragment order keyfrag_kernel wrote) arrive by LDS-DMA in phases of 2 tiles through a 3-slot
 // ring shared by the 4 waves, one barrier per phase; per tile and wave 4 x 8 MFMAs.  Two
