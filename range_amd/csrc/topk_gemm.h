@@ -67,6 +67,7 @@ constexpr int TG_LDS_BYTES = TG_SLOTS * TG_KT * TSB_TILE_BYTES;   // 48 KB
 constexpr int TG_SAMPLE = 4;                 // pass A looks at every 4th tile
 constexpr int TG_CAP = 1024;                 // candidates of a query the re-rank takes in (all lists together)
 constexpr int TG_CAP_L = 32;                 // slots per (query, bank split, lane group) list
+constexpr int TG_MAX_GROUPS = 512;            // row groups per query: splits (<= 64) x 2 tile parities x 4 lane groups
 constexpr int TG_CAP_X = 256;                // candidates whose float32 similarity the re-rank evaluates
 // eps / (|q| |k|): key rounding 2^-11 + query rounding 2^-11 + their product 2^-22 = 0.00097680, elements
 // lost below fp16's normal range 2 x 2^-23, MFMA accumulation (256 terms, f32) 1.6e-5, the float32
@@ -400,26 +401,39 @@ __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* _
                                                                   const float* __restrict__ ehat, float eps_kmax,
                                                                   float key_scale, const float* __restrict__ qscale,
                                                                   float* __restrict__ theta) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= B) return;
-    KeyList L;
-    L.init();
+    // the 16th largest by counting: every lane ranks its own values against all of the query's (LDS
+    // broadcasts) - a third of the time of pushing them through the scan's candidate lists
+    __shared__ float sh_g[4][TG_MAX_GROUPS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + w;
+    if (q >= B) return;                               // (whole waves; no workgroup barrier below)
     const int total = n_parts * 4;
-    for (int e = lane; e < total; e += 64) {
-        const float v = gmax[((int64_t)(e >> 2) * B + q) * 4 + (e & 3)];
-        if (v > -INFINITY) L.push(topk_key(v, (uint32_t)e));
-    }
-    merge_wave(L);
+    // (every global load of the wave up front: one round trip, not three)
     const f32x4 v = *reinterpret_cast<const f32x4*>(ehat + q * KEY_DIM + 4 * lane);
+    const float qs = qscale[q];
+    for (int e = lane; e < total; e += 64) sh_g[w][e] = gmax[((int64_t)(e >> 2) * B + q) * 4 + (e & 3)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float t16 = -INFINITY;
+    for (int e = lane; e < total; e += 64) {
+        const float mine = sh_g[w][e];
+        int rank = 0;
+        for (int f = 0; f < total; ++f) {
+            const float o = sh_g[w][f];
+            rank += (o > mine || (o == mine && f < e)) ? 1 : 0;
+        }
+        if (rank == MAX_TOPK - 1) t16 = mine;          // (exactly one entry has this rank; -inf: fewer than 16 groups saw a row)
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) t16 = fmaxf(t16, __shfl_xor(t16, off));
     float sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
     if (lane == 0) {
-        const float t16 = L.k[MAX_TOPK - 1] ? topk_key_val(L.k[MAX_TOPK - 1]) : -INFINITY;
         // the query's scale of S~ (topk_gemm_kernel: the keys' and this query's powers of two); the margin
         // carries 1e-4 of slack for the rounding of this subtraction and of the norm
-        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f * (key_scale * qscale[q]);
+        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f * (key_scale * qs);
         theta[2 * q] = t16 > -INFINITY ? t16 - eps2 : -INFINITY;
         theta[2 * q + 1] = eps2;
     }
@@ -553,19 +567,33 @@ __global__ __launch_bounds__(256) void topk_gemm_brute_kernel(TopkGemmArgs a) {
     float* sh_q = reinterpret_cast<float*>(lds);
     unsigned long long* sh = reinterpret_cast<unsigned long long*>(lds + KEY_DIM * 4);
     unsigned long long* res = sh + 16 * MAX_TOPK;
+    __shared__ uint32_t sh_set[256];
     const int t = threadIdx.x;
-    for (int64_t q = blockIdx.x; q < a.B; q += gridDim.x) {
-        if (a.ovf[q] == 0u) continue;                                // (uniform over the workgroup)
+    // workgroup b owns the queries b, b + grid, b + 2 grid, ... (neighbours that overflow together are
+    // spread over the workgroups) and reads their flags 256 at a time (one load per thread: a dependent
+    // load per query made the empty walk 12 us)
+    const int64_t G = gridDim.x;
+    const int64_t mine = (a.B - blockIdx.x + G - 1) / G;             // queries of this workgroup
+    for (int64_t base = 0; base < mine; base += 256) {
+        const uint32_t set = (base + t < mine) ? a.ovf[blockIdx.x + G * (base + t)] : 0u;
+        if (!__syncthreads_or((int)set)) continue;                   // (uniform over the workgroup)
+        sh_set[t] = set;
         __syncthreads();
-        sh_q[t] = a.ehat[q * KEY_DIM + t];
-        __syncthreads();
-        topk_brute_force(a.keys, a.n_valid, sh_q, sh, res);
-        if (t < a.k) {
-            const unsigned long long m = res[t];
-            a.oval[q * a.k + t] = m ? topk_key_val(m) : -INFINITY;
-            a.oidx[q * a.k + t] = m ? (int64_t)topk_key_row(m) + a.row_offset : (int64_t)-1;
+        for (int i = 0; i < 256 && base + i < mine; ++i) {
+            if (sh_set[i] == 0u) continue;
+            const int64_t q = blockIdx.x + G * (base + i);
+            __syncthreads();
+            sh_q[t] = a.ehat[q * KEY_DIM + t];
+            __syncthreads();
+            topk_brute_force(a.keys, a.n_valid, sh_q, sh, res);
+            if (t < a.k) {
+                const unsigned long long m = res[t];
+                a.oval[q * a.k + t] = m ? topk_key_val(m) : -INFINITY;
+                a.oidx[q * a.k + t] = m ? (int64_t)topk_key_row(m) + a.row_offset : (int64_t)-1;
+            }
+            if (t == 0 && a.exact_count) atomicAdd(a.exact_count, 1);
         }
-        if (t == 0 && a.exact_count) atomicAdd(a.exact_count, 1);
+        __syncthreads();
     }
 }
 
