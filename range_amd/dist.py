@@ -83,7 +83,7 @@ class ShardedRange:
         #: RANGE_DIST_BLOCKING=1: every collective is waited for where it is issued (no overlap with
         #: compute, one pass 1 over all scanned queries) - the escape hatch for bisecting a hang or a
         #: wrong result on a backend the overlapped schedule has not met (it has run over gloo and
-        #: the in-process test backend only; RCCL with more than one rank has not executed)
+        #: the in-process test backend, and over RCCL with ONE rank; with more than one rank it has not executed)
         self.blocking = os.environ.get("RANGE_DIST_BLOCKING", "0") == "1"
         if self.blocking:
             self.pass1_chunked = False

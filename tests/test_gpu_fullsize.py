@@ -153,16 +153,17 @@ def test_c3_range_db_large_100k_queries(tmp_path):
 def test_small_batches_at_full_size(tmp_path):
     """The latency path at the benchmark's sizes (range_db_large, L = 40, H = 512): 1 / 16 / 17 / 32
     queries run the persistent encoder launch and ONE pass over the bank (attend_small.h, one or two
-    query tiles per workgroup), 33 and 512 queries the persistent encoder and the two-pass kernels.
+    query tiles per workgroup), 33 / 64 / 128 / 512 queries the persistent encoder and the two-pass kernels,
+    1 250 (a rank of 8's share of BASELINE's batch) the persistent encoder at 79 tiles (its parts taken in turns).
     Every row against the float64 oracle and the reference's float32 order, against the same rows of
     one large batch (other kernels, other summation orders: float32 rounding), bit-identical when
     repeated, and the numpy contract returns the same bits."""
     N = synth.BANK_ROWS["range_db_large"]
     m, obank, w = _model(tmp_path, N)
-    q = synth.make_queries(1024, seed=11)
+    q = synth.make_queries(2304, seed=11)
     x = torch.from_numpy(q).to("cuda:0")
     big = m(x, return_device=True).cpu().numpy()
-    for B in (1, 16, 17, 32, 33, 512):
+    for B in (1, 16, 17, 32, 33, 64, 128, 512, 1250):
         m.engine.profile_enable(True)
         out = m(x[:B], return_device=True)
         one_pass = m.engine.profile_read(1)[1] == 0          # no pass 1 ran

@@ -17,7 +17,14 @@ the 2-D layouts, device-resident buffers without host staging.
   drop-in   ``model(coords)`` with the same batch on every rank returns the full batch on every rank;
             the sharded ``save_embeddings`` moves every rank's rows to rank 0 only.
 
-The same shapes run on every box as two gloo ranks sharing one GPU (tests/test_gpu_sharded.py)."""
+The same shapes run on every box as two gloo ranks sharing one GPU (tests/test_gpu_sharded.py).
+
+``test_rccl_single_rank_stream_semantics`` needs ONE GPU: a one-rank RCCL group.  Its collectives move
+nothing between devices, but they are ProcessGroupNCCL's - enqueued on the backend's own stream,
+``work.wait()`` a stream dependency instead of a host wait - which neither gloo nor the rank threads
+provide: the chunked, overlapped schedule of range_amd/dist.py (forced to 2 and 4 chunks) then runs
+with real asynchrony between the compute stream and the collectives' stream, and a missing
+dependency shows as a result that differs from the one-GPU model's or from its own repeat."""
 import os
 import socket
 
@@ -62,7 +69,7 @@ def _sample_check(out_rows, q_rows, obank, w, betas):
         np.testing.assert_allclose(got, O.retrieve(e, q_rows, obank, "RANGE+", b), rtol=0, atol=1e-4)
 
 
-def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
+def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl", body=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
@@ -73,7 +80,7 @@ def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl"):
         dev = torch.device("cuda", 0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _body(rank, world, dev, ck, rbank, tmp, backend)
+        (body or _body)(rank, world, dev, ck, rbank, tmp, backend)
         ret[rank] = "ok"
     except Exception as ex:  # noqa: BLE001
         import traceback
@@ -185,3 +192,84 @@ def test_rccl_row_sharded_at_c4_c5_shapes(tmp_path):
     ret = mp.Manager().dict()
     mp.spawn(_rank, args=(world, _free_port(), ck, rbank, str(tmp_path), ret, backend), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def _body_single(rank, world, dev, ck, rbank, tmp, backend):
+    """One RCCL rank: the sharded model over the whole bank against the plain one-GPU model."""
+    import torch.distributed as dist
+    from oracle import range_oracle as O
+    from range_amd import load_model
+    from range_amd.save import save_embeddings
+    from tools import synth
+    assert world == 1 and dist.get_backend() == "nccl"
+    obank = O.prep_bank(*_bank_arrays())
+    w = synth.make_encoder_weights(L, H, 256, 2, SEED)
+    plain = load_model("RANGE+", pretrained_path=ck, device=dev, db_path=rbank, beta=0.5)
+    m = load_model("RANGE+", pretrained_path=ck, device=dev, db_path=rbank, beta=0.5, shards=1)
+    B = 20_000 + 37
+    q = synth.make_queries(B, seed=71, lat_max=90.0)
+    x = torch.from_numpy(q).to(dev)
+    ref = plain(x, return_device=True)
+    outs = {}
+    for n_chunks in (1, 2, 4):
+        m.sharded.n_chunks = n_chunks
+        m.sharded.comm_timing(True)
+        out = m(x, local=True, return_device=True)
+        comm = m.sharded.comm_timing(False)
+        assert comm["total"] >= 0.0
+        for _ in range(2):            # a race between the two streams would not repeat itself bit for bit
+            assert torch.equal(m(x, local=True, return_device=True), out), n_chunks
+        d = (out - ref).abs()
+        assert float(d[:, 1024:].max()) == 0.0                     # the encoder does not know about shards
+        assert float(d[:, 2:1024].max()) < 2e-6 and float(d[:, :2].max()) < 5e-5, (n_chunks, float(d.max()))
+        outs[n_chunks] = out
+    # the chunking changes nothing: same bank splits, statistics merged in rank order
+    Bs = 9984
+    m.sharded.n_chunks = 4
+    chunked = m.sharded.forward(x[:Bs].contiguous())
+    m.sharded.pass1_chunked = False
+    try:
+        unchunked = m.sharded.forward(x[:Bs].contiguous())
+    finally:
+        m.sharded.pass1_chunked = True
+    assert torch.equal(chunked, unchunked)
+    idx = np.sort(np.random.default_rng(3).choice(B, 96, replace=False))
+    sel = torch.from_numpy(idx).to(dev)
+    _sample_check(outs[4][sel].cpu().numpy()[None], q[idx], obank, w, (0.5,))
+    # top-k and the beta sweep through the same collectives
+    tv, ti = m.topk(x[sel], 16, local=True)
+    pv, pi = plain.topk(x[sel], 16)
+    assert torch.equal(ti.cpu(), torch.as_tensor(pi).cpu()) and torch.equal(tv.cpu(), torch.as_tensor(pv).cpu())
+    betas = (0.0, 0.5, 1.0)
+    m.sharded.n_chunks = 2
+    sw = m.sweep(x[:Bs], betas, local=True, return_device=True)
+    si = np.sort(np.random.default_rng(4).choice(Bs, 48, replace=False))
+    _sample_check(sw[:, torch.from_numpy(si).to(dev)].cpu().numpy(), q[si], obank, w, betas)
+    # the batch driver: results travel to rank 0 (itself) behind the next batch's compute
+    from argparse import Namespace
+
+    def loader(n_batches, bs):
+        for i in range(n_batches):
+            n = bs if i + 1 < n_batches else bs - 37
+            yield torch.from_numpy(synth.make_queries(n, seed=900 + i)), torch.arange(n, dtype=torch.float32)
+    a = Namespace(embeddings_dir=os.path.join(tmp, "emb1"), location_model_name="RANGE+", task_name="t")
+    save_embeddings(a, loader(4, 1500), loader(2, 300), m)
+    z = np.load(os.path.join(tmp, "emb1", "RANGE+", "t_train.npz"))
+    assert z["embeddings"].shape == (4 * 1500 - 37, 1280)
+    want = plain(torch.from_numpy(z["coords"]).to(dev), return_device=True).cpu().numpy()
+    np.testing.assert_allclose(z["embeddings"], want, rtol=0, atol=5e-5)
+    # (the encoder's kernels differ by batch size - 1 500 per batch there, 5 963 at once here: float64 rounding)
+    np.testing.assert_allclose(z["embeddings"][:, 1024:], want[:, 1024:], rtol=0, atol=1e-13)
+
+
+def test_rccl_single_rank_stream_semantics(tmp_path):
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    from range_amd.bank import prepare_bank
+    from range_amd.bankfile import write_bankfile
+    from tools import synth
+    ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=SEED)
+    rbank = write_bankfile(str(tmp_path / "large.rbank"), prepare_bank(*_bank_arrays()))
+    ret = mp.Manager().dict()
+    mp.spawn(_rank, args=(1, _free_port(), ck, rbank, str(tmp_path), ret, "nccl", _body_single), nprocs=1, join=True)
+    assert dict(ret) == {0: "ok"}, dict(ret)
