@@ -1115,16 +1115,19 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
     const bool fused = c->topks_fused && B <= n_wg;
     // (the candidate lists of a call are addressed by 32-bit byte offsets: B x lists x 256 B < 4 GB - the
     // Python layer calls in chunks of 16 384 queries = 1 GB at most)
-    if (c->topk_gemm && bf16 && B > 256 && n_blocks >= 64 && !c->topks_force_exact && B <= 60000) {
+    // (a bank whose largest key norm is so far from 1 that no power of two brings it into fp16's range - or
+    // that is all zeros - keeps the streaming scan)
+    int tg_e2 = 0;
+    (void)std::frexp((double)c->key_norm_max, &tg_e2);                  // key_norm_max < 2^e2
+    const bool tg_bank_ok = c->key_norm_max > 0.f && std::isfinite(c->key_norm_max) && std::abs(14 - tg_e2) <= 100;
+    if (c->topk_gemm && bf16 && B > 256 && n_blocks >= 64 && !c->topks_force_exact && B <= 60000 && tg_bank_ok) {
         // batches beyond the one-launch regime: GEMM-shaped, list-free (topk_gemm.h): group maxima ->
         // per-query threshold -> candidates -> float32 re-rank.  Two workgroups per CU; the splits fill
         // one round of them (at least 4: 32 row groups for the threshold; at least 8 tiles each).
         TopkGemmArgs ga{};
         if (c->tg_key_scale == 0.f) {
             // the fp16 copy of the keys, scaled so that the largest row norm lies in [2^13, 2^14)
-            int e2 = 0;
-            (void)std::frexp((double)c->key_norm_max, &e2);            // key_norm_max < 2^e2
-            const float ks = (float)std::ldexp(1.0, std::max(-100, std::min(100, 14 - e2)));   // (finite for any norm)
+            const float ks = (float)std::ldexp(1.0, 14 - tg_e2);
             const int64_t n_tiles = c->n_pad / BLK;
             HIP_TRY(c->d_keys_f16.ensure((size_t)n_tiles * (TSB_TILE_BYTES / 4)));
             const int64_t threads = n_tiles * 8 * 64;
@@ -1184,7 +1187,9 @@ static int topk_stream_impl(range_ctx* c, const float* ehat32, int64_t B, int32_
                 hipLaunchKernelGGL(topk_gemm_kernel<0>, ggrid, dim3(TG_WAVES * 64), TG_LDS_BYTES, s, ga);
                 ga.tile_stride = 1;
                 hipLaunchKernelGGL(topk_gemm_threshold_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, ga.gmax,
-                                   ga.n_splits * 2, B, ehat32, TG_EPS_REL * c->key_norm_max, c->tg_key_scale, c->ws_tg_qscale.p, c->ws_tg_theta.p);
+                                   ga.n_splits * 2, B, ehat32, (float)((double)TG_EPS_REL * (double)c->key_norm_max * (double)c->tg_key_scale),
+                                   c->key_norm_max > 0.f ? (float)std::log2((double)c->key_norm_max) : -INFINITY,
+                                   c->ws_tg_qscale.p, c->ws_tg_theta.p);
 #ifdef RANGE_EXP_TG_NOHIT       // timing experiment: pass B with a threshold nothing reaches (its MFMA + compare floor)
                 HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->ws_tg_theta.p, 0x7f800000, (size_t)B * 2, s));
 #endif

@@ -393,13 +393,17 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
     }
 }
 
-// theta[q] = {(the 16th largest of the query's n_parts x 4 group maxima) - 2 eps, 2 eps}, eps = eps_kmax |q|
-// in the query's scale of S~
+// theta[q] = {(the 16th largest of the query's n_parts x 4 group maxima) - 2 eps, 2 eps}, eps = eps_rel |q| max|k|
+// in the query's scale of S~ (eps_ks = eps_rel x max|k| x the keys' scale; the norm is taken of the SCALED
+// query: neither factor can under- or overflow, whatever the magnitudes of bank and queries)
 // (with 1e-4 of slack for the rounding of the norm and of the subtraction);
-// -inf when fewer than 16 groups saw a row (every row is then a candidate).  One wave per query.
+// -inf when fewer than 16 groups saw a row (every row is then a candidate), and for a query whose float32
+// products themselves leave the normal range (|q| max|k| below 2^-90 or above 2^100, the zero query
+// included: the error bound of the float32 chain does not hold there) - its lists overflow and it is
+// answered by brute force.  One wave per query.
 __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* __restrict__ gmax, int n_parts, int64_t B,
-                                                                  const float* __restrict__ ehat, float eps_kmax,
-                                                                  float key_scale, const float* __restrict__ qscale,
+                                                                  const float* __restrict__ ehat, float eps_ks,
+                                                                  float log2_kmax, const float* __restrict__ qscale,
                                                                   float* __restrict__ theta) {
     // the 16th largest by counting: every lane ranks its own values against all of the query's (LDS
     // broadcasts) - a third of the time of pushing them through the scan's candidate lists
@@ -427,15 +431,17 @@ __global__ __launch_bounds__(256) void topk_gemm_threshold_kernel(const float* _
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) t16 = fmaxf(t16, __shfl_xor(t16, off));
-    float sq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    const f32x4 vs = v * qs;                            // (exact: a power of two; largest element in [2^13, 2^14))
+    float sq = vs.x * vs.x + vs.y * vs.y + vs.z * vs.z + vs.w * vs.w;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
     if (lane == 0) {
-        // the query's scale of S~ (topk_gemm_kernel: the keys' and this query's powers of two); the margin
-        // carries 1e-4 of slack for the rounding of this subtraction and of the norm
-        const float eps2 = 2.0f * eps_kmax * sqrtf(sq) * 1.0001f * (key_scale * qs);
-        theta[2 * q] = t16 > -INFINITY ? t16 - eps2 : -INFINITY;
-        theta[2 * q + 1] = eps2;
+        // the margin carries 1e-4 of slack for the rounding of this subtraction and of the norm
+        const float eps2 = 2.0f * eps_ks * sqrtf(sq) * 1.0001f;
+        const float l2 = 0.5f * log2f(sq) - log2f(qs) + log2_kmax;       // log2(|q| max|k|); -inf for a zero query or bank
+        const bool normal = l2 >= -90.0f && l2 <= 100.0f;
+        theta[2 * q] = (normal && t16 > -INFINITY) ? t16 - eps2 : -INFINITY;
+        theta[2 * q + 1] = normal ? eps2 : 0.0f;
     }
 }
 

@@ -971,7 +971,7 @@ struct TopkMergeLds {
           sh_head(reinterpret_cast<uint32_t*>(lds + TOPKM_OFF_HEAD)),
           sh_q(reinterpret_cast<float*>(lds + TOPKM_OFF_Q)),
           sh_d(reinterpret_cast<float*>(lds + TOPKM_OFF_F)),          // [4] dmax per wave (ordered bits)
-          sh_n2(reinterpret_cast<float*>(lds + TOPKM_OFF_F) + 4),     // [4] |q|^2 per wave
+          sh_n2(reinterpret_cast<float*>(lds + TOPKM_OFF_F) + 4),     // [4] the waves' shares of |q| (norms, not squares)
           sh_i(reinterpret_cast<int*>(lds + TOPKM_OFF_I)) {}          // survivor count, flag
 };
 
@@ -984,10 +984,19 @@ __device__ void topk_merge_prefetch(char* lds, int64_t q, const TopkStreamArgs& 
     const int p = threadIdx.x;                                        // blockDim.x == 256 == KEY_DIM
     const float v = a.ehat[q * KEY_DIM + p];
     m.sh_q[p] = v;
-    float sq = v * v;
+    // the wave's share of |q|, taken of the elements times the power of two that brings the wave's largest
+    // near 1 (a query of norm 1e-25 squared in float32 is 0 - and a zero error bound made the merge hand out
+    // the APPROXIMATE values as if they were exact; found by tests/test_gpu_topk_gemm.py in round 5)
+    float mx = fabsf(v);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const uint32_t mE = (__float_as_uint(mx) >> 23) & 0xFFu;
+    const float up = (mE >= 1u && mE <= 253u) ? __uint_as_float((254u - mE) << 23) : 1.0f;     // 2^(127 - E)
+    const float vs = v * up;
+    float sq = vs * vs;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) sq += __shfl_xor(sq, off);
-    if ((p & 63) == 0) m.sh_n2[p >> 6] = sq;
+    if ((p & 63) == 0) m.sh_n2[p >> 6] = sqrtf(sq) / up;              // (a NORM per wave, not a square)
     if (p == 0) { m.sh_i[0] = 0; m.sh_i[1] = 0; }
     if (p < MAX_TOPK) m.res[p] = 0ull;
 }
@@ -1139,8 +1148,13 @@ __device__ void topk_merge_query(char* lds, int64_t q, const TopkStreamArgs& a, 
     }
     const float dall = fmaxf(fmaxf(m.sh_d[0], m.sh_d[1]), fmaxf(m.sh_d[2], m.sh_d[3]));
     float eps2 = 0.f;
-    if (a.eps_rel > 0.f)   // (a bound, not a result: 1 % over the norm covers its rounding)
-        eps2 = 2.f * a.eps_rel * 1.01f * sqrtf(m.sh_n2[0] + m.sh_n2[1] + m.sh_n2[2] + m.sh_n2[3]) * a.kmax;
+    const bool approx = a.eps_rel > 0.f;        // prefilter form: the candidates' values are approximate
+    if (approx) {          // (a bound, not a result: 1 % over the norm covers its rounding)
+        const float nm = fmaxf(fmaxf(m.sh_n2[0], m.sh_n2[1]), fmaxf(m.sh_n2[2], m.sh_n2[3]));
+        float r2 = 0.f;
+        for (int i = 0; i < 4; ++i) { const float r = nm > 0.f ? m.sh_n2[i] / nm : 0.f; r2 += r * r; }
+        eps2 = 2.f * a.eps_rel * 1.01f * (nm * sqrtf(r2)) * a.kmax;
+    }
     if (eps2 > 0.f && T != 0u) T = topk_ordered_bits(topk_key_val((unsigned long long)T << 32) - eps2);
     // ---- 2. survivors: the entries >= T - the first c of a thread's sorted list - compacted into
     //      LDS; list position by list position while any lane still has one, the lanes of a wave
@@ -1183,7 +1197,7 @@ __device__ void topk_merge_query(char* lds, int64_t q, const TopkStreamArgs& a, 
         // dropped (approximate) value with the k-th exact one, 2 eps apart.
         const int sub = p & 3;
         const int n64 = S > 64 ? 2 : 1;
-        if (eps2 > 0.f) topk_exact_values(a, m.sh_q, lds + TOPKM_OFF_X, m.surv, m.surv2, S, -INFINITY);
+        if (approx) topk_exact_values(a, m.sh_q, lds + TOPKM_OFF_X, m.surv, m.surv2, S, -INFINITY);
         else if (sub == 3) {
             for (int rr = 0; rr < n64; ++rr) { const int t = 64 * rr + (p >> 2); m.surv2[t] = t < S ? m.surv[t] : 0ull; }
         }
@@ -1220,7 +1234,7 @@ __device__ void topk_merge_query(char* lds, int64_t q, const TopkStreamArgs& a, 
         __syncthreads();
         const unsigned long long kth = m.res[k - 1];
         unsafe = a.force_exact || (kth != 0ull && dall >= topk_key_val(kth) - eps2) || (kth == 0ull && dall > -INFINITY);
-        if (!unsafe && eps2 > 0.f) {
+        if (!unsafe && approx) {
             const float vmin = kth != 0ull ? topk_key_val(kth) - eps2 : -INFINITY;
             __syncthreads();                                   // (every thread has read res)
             if (p < MAX_TOPK) m.res[p] = 0ull;

@@ -123,3 +123,48 @@ def test_gemm_topk_overflowing_lists_fall_back_to_brute_force(monkeypatch):
     assert gemm.topk_stream_exact_count() >= 5
     s64 = q[:5].astype(np.float64) @ keys.astype(np.float64).T
     assert np.all(np.take_along_axis(s64, ai[:5].cpu().numpy(), 1) >= np.sort(s64, axis=1)[:, -16][:, None] - 1e-6)
+
+
+@pytest.mark.parametrize("key_scale", [1e-20, 1.0, 3.0e3])
+def test_gemm_topk_operand_scales(key_scale, monkeypatch):
+    """The fp16 operands of the GEMM passes are the keys and queries times powers of two chosen from
+    their magnitudes (topk_gemm.h): banks and queries far from unit scale, queries with one dominant
+    element (the others sink towards fp16's subnormals after scaling), rows of very different norms and
+    an all-zero query (every row ties: lists overflow, brute force) must still give the float32 scan's
+    values and indices bit for bit."""
+    rng = np.random.default_rng(77)
+    N, B = 20_011, 400
+    keys = _unit(rng, N) * np.float32(key_scale)
+    keys[::7] *= np.float32(1e-3)                       # rows of very different norms
+    keys[5::101] *= np.float32(0.25)
+    q = _unit(rng, B)
+    q[0:40] *= np.float32(1e-30)
+    q[40:80] *= np.float32(1e20)
+    spike = rng.integers(0, 256, 40)
+    q[80:120] *= np.float32(1e-6)
+    q[np.arange(80, 120), spike] = 1.0                  # one element a million times the rest
+    q[120:160, 1:] = 0.0                                # a single non-zero element
+    q[160] = 0.0                                        # the zero query
+    gemm, stream = _engines(monkeypatch, keys)
+    e = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+    for k in (16, 5):
+        av, ai = gemm.topk_stream(e, k)
+        bv, bi = stream.topk_stream(e, k)
+        assert torch.equal(ai, bi) and torch.equal(av, bv), k
+    assert bool(torch.isfinite(av).all())
+    s64 = q.astype(np.float64) @ keys.astype(np.float64).T
+    rv, ri = O.topk64(s64, 16)
+    av, ai = gemm.topk_stream(e, 16)
+    got = ai.cpu().numpy()[161:]
+    assert int((got != ri[161:]).any(axis=1).sum()) <= 3      # (float32 near-ties)
+    # the VALUES are float32 similarities at every magnitude (round 5: the streaming scan handed out its
+    # bf16 approximations for queries whose squared norm underflows float32 - and agreed with itself)
+    scale = (np.linalg.norm(q.astype(np.float64), axis=1) * np.linalg.norm(keys.astype(np.float64), axis=1).max())[:, None]
+    ok = scale[:, 0] >= 1e-33          # (where float32 can hold the products at all)
+    assert ok.sum() >= 359 and float((np.abs(av.cpu().numpy() - rv)[ok] / scale[ok]).max()) < 2e-6
+    # ... and from the one-launch regime of the streaming scan (<= 256 queries) as well
+    for lo in (0, 40, 80):
+        sv, si = gemm.topk_stream(e[lo:lo + 40].contiguous(), 16)
+        if ok[lo:lo + 40].all():
+            assert float((np.abs(sv.cpu().numpy() - rv[lo:lo + 40]) / scale[lo:lo + 40]).max()) < 2e-6
+            assert int((si.cpu().numpy() != ri[lo:lo + 40]).any(axis=1).sum()) <= 2
