@@ -17,6 +17,7 @@ rows, encodes 10 000 / W queries and scans the 10 000 / Q queries of its group.
 --cold: the protocol of rounds 2-4 (2 warm-up steps, 5 timed): a rank's 3 ms steps are then timed while
 the chip is still raising its clock after idling (round 5, tools/clock_ramp.py: the first ~35 ms of
 activity run up to 25 % slower) - the default now warms up for >= 150 ms and times 40 steps.
+SHARD_P1_SPLITS=n: pass 1 of every chunk with n bank splits instead of the engine's choice (A/B).
 Usage: python tools/shard_emulate.py [--json] [--cold] [--chunks k] [--layouts W] [--unchunked-pass1] [N ...]"""
 import json
 import os
@@ -66,6 +67,8 @@ for mode, WT, W in cases:                                       # W = ranks of a
         # chunk-major order of the scanned queries (ShardedRange._scan), pass 1 per chunk with the
         # same bank splits, the shards' statistics merged in rank order (here: W copies of the own)
         ns1 = eng.p1_splits(W * max(hi - lo for lo, hi in zip(cuts[:-1], cuts[1:])))
+        if os.environ.get("SHARD_P1_SPLITS"):          # (A/B of the chunks' bank-split count)
+            ns1 = int(os.environ["SHARD_P1_SPLITS"])
         UNCHUNKED = "--unchunked-pass1" in sys.argv
 
         def step():
