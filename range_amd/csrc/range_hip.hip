@@ -364,24 +364,35 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     // A tail of up to 2 048 queries after full rounds runs as the small-batch kernels (its tiles
     // spread over all CUs: ~0.16 ms for 1 808 queries) instead of a round of 16-query workgroups
     // (0.23 ms whatever its fill): 10 000 queries = 256 x 32 + a split tail of 113 tiles.
-    if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split && !only16) {
+    auto main_plus_split_tail = [&](int64_t b_main) -> int {       // -1: not taken
+        const int64_t tail = a.B - b_main;
         int S, KP;
-        choose_encoder_split(c->n_cu, a.n_slots, a.H, (rem + 15) / 16, S, KP);
-        if (S * KP > 1 && split_width_ok(a.H, S)) {
-            const int64_t b_main = a.B - rem;
-            EncArgs m = a;
-            m.B = b_main;
-            int rc = launch_encoder(c, m, s);          // (whole rounds of 32-query workgroups)
-            if (rc) return rc;
-            EncArgs t = a;
-            t.B = rem;
-            t.lonlat = a.lonlat + 2 * b_main;
-            t.ehat64 = a.ehat64 + ENC_EMBED * b_main;
-            t.eraw64 = a.eraw64 ? a.eraw64 + ENC_EMBED * b_main : nullptr;
-            t.ehat32 = a.ehat32 + ENC_EMBED * b_main;
-            t.xq = a.xq + 4 * b_main;
-            return launch_encoder_split(c, t, S, KP, s);
-        }
+        choose_encoder_split(c->n_cu, a.n_slots, a.H, (tail + 15) / 16, S, KP);
+        if (S * KP <= 1 || !split_width_ok(a.H, S)) return -1;
+        EncArgs m = a;
+        m.B = b_main;
+        int rc = launch_encoder(c, m, s);              // (whole rounds of equal workgroups)
+        if (rc) return rc;
+        EncArgs t = a;
+        t.B = tail;
+        t.lonlat = a.lonlat + 2 * b_main;
+        t.ehat64 = a.ehat64 + ENC_EMBED * b_main;
+        t.eraw64 = a.eraw64 ? a.eraw64 + ENC_EMBED * b_main : nullptr;
+        t.ehat32 = a.ehat32 + ENC_EMBED * b_main;
+        t.xq = a.xq + 4 * b_main;
+        return launch_encoder_split(c, t, S, KP, s);
+    };
+    if (full_rounds > 0 && rem > 0 && rem <= 2048 && c->enc_split && c->enc_tail_split && !only16) {
+        const int rc = main_plus_split_tail(a.B - rem);
+        if (rc >= 0) return rc;
+    }
+    // A batch a little over one round of 16-query workgroups (4 097 .. 5 376 queries on 256 CUs: what a rank
+    // of 2 encodes of BASELINE's batch) would fill 60 % of a round of 32-query workgroups and take that
+    // round's whole time (0.40 ms): a full round of 16-query workgroups (0.24 ms) + a split tail (<= 0.13 ms)
+    const int64_t round16 = (int64_t)16 * c->n_cu;
+    if (full_rounds == 0 && a.B > round16 && a.B - round16 <= 1280 && c->enc_split && c->enc_tail_split && !only16) {
+        const int rc = main_plus_split_tail(round16);
+        if (rc >= 0) return rc;
     }
     int grid;
     if (only16 || a.B <= (int64_t)16 * c->n_cu) {

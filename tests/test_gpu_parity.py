@@ -681,10 +681,11 @@ def test_forward_without_kept_logits_is_identical(tmp_path, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("B", [8192 + 1, 10000, 8192 + 4096, 8192 + 4097, 3 * 8192 + 77])
+@pytest.mark.parametrize("B", [4096 + 1, 5000, 4096 + 1280, 4096 + 1281, 8192 + 1, 10000, 8192 + 4096, 8192 + 4097, 3 * 8192 + 77])
 def test_encoder_large_batch_geometry(B):
-    """Batches beyond one round of 32-query workgroups: the last round may run as 16-query
-    workgroups (10 000 = 256 x 32 + 113 x 16); every query must still come out right, in order."""
+    """Batches beyond one round of workgroups: the last round may run as 16-query workgroups or as the
+    split small-batch kernels (10 000 = 256 x 32 + a split tail of 113 tiles; 5 000 = 256 x 16 + a split tail
+    of 57 tiles); every query must still come out right, in order."""
     w, enc = _params(10, 256, 2, 5)              # H = 256: the 16-wave kernel
     eng = _engine(enc)
     q = synth.make_queries(B, seed=B, lat_max=60.0)

@@ -43,7 +43,7 @@ python3 $R/tools/latency.py > $O/latency_plain.log 2>&1
 # protocol / layouts), the clock ramp behind the difference, the mid-size encoder A/B
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/topk -o tk -- python3 $R/tools/topk_batch.py 10000 100000 > $O/topk_batch.log 2>&1
 find $O/topk -name "*kernel_stats.csv" -exec cp {} $O/topk_batch_kernel_stats.csv \;
-python3 $R/tools/shard_emulate.py 1 8 > $O/shard_emulate_steady.log 2>&1
+python3 $R/tools/shard_emulate.py 1 2 4 8 > $O/shard_emulate_steady.log 2>&1
 python3 $R/tools/shard_emulate.py --chunks 1 8 > $O/shard_emulate_one_chunk.log 2>&1
 python3 $R/tools/shard_emulate.py --cold 8 > $O/shard_emulate_cold_protocol.log 2>&1
 python3 $R/tools/shard_emulate.py --layouts 8 > $O/shard_emulate_layouts.log 2>&1
