@@ -390,8 +390,9 @@ int launch_encoder(range_ctx* c, const EncArgs& a_in, hipStream_t s) {
     // of 2 encodes of BASELINE's batch) would fill 60 % of a round of 32-query workgroups and take that
     // round's whole time (0.40 ms): a full round of 16-query workgroups (0.24 ms) + a split tail (<= 0.13 ms)
     const int64_t round16 = (int64_t)16 * c->n_cu;
-    if (full_rounds == 0 && a.B > round16 && a.B - round16 <= 1280 && c->enc_split && c->enc_tail_split && !only16) {
-        const int rc = main_plus_split_tail(round16);
+    // (the same behind full rounds of 32-query workgroups: 8 192 k + 4 097 .. 5 376 queries)
+    if (rem > round16 && rem - round16 <= 1280 && c->enc_split && c->enc_tail_split && !only16) {
+        const int rc = main_plus_split_tail(a.B - (rem - round16));
         if (rc >= 0) return rc;
     }
     int grid;

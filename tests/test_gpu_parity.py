@@ -681,7 +681,7 @@ def test_forward_without_kept_logits_is_identical(tmp_path, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("B", [4096 + 1, 5000, 4096 + 1280, 4096 + 1281, 8192 + 1, 10000, 8192 + 4096, 8192 + 4097, 3 * 8192 + 77])
+@pytest.mark.parametrize("B", [4096 + 1, 5000, 4096 + 1280, 4096 + 1281, 8192 + 1, 10000, 8192 + 4096, 8192 + 4097, 8192 + 5000, 3 * 8192 + 77])
 def test_encoder_large_batch_geometry(B):
     """Batches beyond one round of workgroups: the last round may run as 16-query workgroups or as the
     split small-batch kernels (10 000 = 256 x 32 + a split tail of 113 tiles; 5 000 = 256 x 16 + a split tail
