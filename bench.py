@@ -171,8 +171,16 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
             t_re += t3 - t2
         return t_sh, t_si, t_re
 
-    n_all = torch.get_num_threads()
-    host = f"host: {cpu_model_name()}, {os.cpu_count()} logical CPUs"
+    # every CPU this process may run on, whatever OMP_NUM_THREADS the launcher exported (torchrun sets 1
+    # for N > 1, this file's own launcher cpu_count / N): the baseline does not depend on --gpus
+    n_prev = torch.get_num_threads()
+    try:
+        n_all = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_all = os.cpu_count() or n_prev
+    n_all = int(os.environ.get("RANGE_CPU_BASELINE_THREADS", "0")) or n_all
+    torch.set_num_threads(n_all)
+    host = f"host: {cpu_model_name()}, {os.cpu_count()} logical CPUs, {n_all} usable by this process = torch threads"
 
     def leg(faithful):
         run(q[:64], 64, faithful)                                  # warm-up
@@ -202,6 +210,7 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     fast["kind"] = "port"
     fast["shape"] = "the same path with the spherical harmonics by the stable recurrence (not what the reference runs)"
     res["port_recurrence"] = fast
+    torch.set_num_threads(n_prev)
     return res
 
 
@@ -254,8 +263,11 @@ def main():
             # rehearsal of the N-rank code path inside ONE process: the ranks are threads sharing cuda:0
             # (tools/thread_ranks.py; a box of this pool admits 6 processes on its card, the north star
             # has 8 ranks).  Every leg of the N-rank bench runs; the timing means nothing.
+            from tools.thread_ranks import run_rank_threads, threaded_backend_available
+            if not threaded_backend_available():
+                raise SystemExit("RANGE_DIST_BACKEND=threads needs torch's in-process 'threaded' process group "
+                                 "(torch.testing._internal.distributed.multi_threaded_pg): not in this torch build")
             import torch
-            from tools.thread_ranks import run_rank_threads
             torch.cuda.init()             # (once, in front of the threads)
             res = run_rank_threads(a.gpus, lambda rank, world: rank_main(a, rank, 0, world, "threads"), timeout=3000.0)
             bad = {r: v for r, v in res.items() if v != "ok"}
@@ -263,11 +275,26 @@ def main():
                 print(bad, file=sys.stderr)
             sys.exit(1 if bad else 0)
         sys.exit(spawn_ranks(a))
-    rank_main(a, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
-              int(os.environ.get("WORLD_SIZE", "1")), backend)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from tools import rank_guard
+    if (world > 1 and backend in ("nccl", "gloo") and not rank_guard.guarded()
+            and os.environ.get("RANGE_BENCH_GUARD", "1") != "0"):
+        # a rank of a multi-process job: THIS process (no torch, no GPU) only guards; the rank's work
+        # runs in a fresh child whose stages it watches.  A first contact that fails or hangs on the
+        # overlapped schedule is answered by a fresh child on the blocking one (tools/rank_guard.py) -
+        # the run still yields a line, with dist.schedule = "blocking-fallback" - and whatever
+        # happens, this rank ends well inside the driver's budget, non-zero when there is no line.
+        dl = {k: float(os.environ[f"RANGE_BENCH_{k.upper()}_TIMEOUT_S"]) for k in rank_guard.DEFAULT_DEADLINES
+              if os.environ.get(f"RANGE_BENCH_{k.upper()}_TIMEOUT_S")}
+        sys.exit(rank_guard.guard_rank([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                       rank_guard.SHARDED_ATTEMPTS, dl,
+                                       float(os.environ.get("RANGE_BENCH_TOTAL_TIMEOUT_S", "540"))))
+    rank_main(a, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world, backend)
 
 
 def rank_main(a, rank, local, world, backend):
+    from tools.rank_guard import report_stage
+    report_stage("init")
     import numpy as np
     import torch
 
@@ -306,7 +333,10 @@ def rank_main(a, rank, local, world, backend):
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, make_layout, shard_rows
         if backend != "threads":          # (the rank threads arrive inside an initialised group)
+            # (timeout: 120 s instead of torch's 600 - RANGE_DIST_TIMEOUT_S; a second attempt of the
+            # rank guard rendezvouses under its own store prefix)
             init_from_env(backend)
+    report_stage("setup")
 
     L, H = 40, a.hidden
     N = synth.BANK_ROWS[a.bank]
@@ -329,6 +359,22 @@ def rank_main(a, rank, local, world, backend):
         eng.set_bank(sh.keys, sh.values, sh.xyz, r0)
         n_local = r1 - r0
         model = ShardedRange(eng, "RANGE+", a.beta, group=shard_group, n_chunks=a.shard_chunks or None)
+
+    # ---- preflight of the sharded step (untimed): the FIRST steps over the job's collectives run under
+    #      the rank guard's shortest deadline, the blocking schedule first (every collective waited for
+    #      where it is issued: the form most likely to work on a backend the schedule has not met), then
+    #      the overlapped one on the same batch; the two are bit-identical by design (dist.py), so
+    #      torch.equal on the results is the check.  A mismatch on ANY rank sends every rank to the
+    #      blocking schedule for the timed legs (dist.schedule = "blocking-fallback"); a hang or a
+    #      failure ends this process - the guard then starts a fresh one with RANGE_DIST_BLOCKING=1,
+    #      where only the blocking step is preflighted
+    preflight = None
+    if sharded:
+        preflight = sharded_preflight(a, model, eng, dist, dev, rank, world, row_shards, shard_group, synth, torch)
+        if preflight["schedule"] != "overlapped" and not model.blocking:
+            model.blocking, model.pass1_chunked = True, False
+            os.environ["RANGE_DIST_BLOCKING"] = "1"       # (the models of the later legs - 2-D layouts - too)
+    report_stage("timed")
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -619,9 +665,24 @@ def rank_main(a, rank, local, world, backend):
             "parity": parity,
         }
         if dist is not None:
-            res["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            from range_amd.dist import dist_timeout_s
+            be = dist.get_backend()
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if be == "nccl" else None
+            except Exception:  # noqa: BLE001
+                rccl = None
+            res["dist"] = {"backend": be, "world_size": dist.get_world_size(), "rccl_version": rccl,
+                           "torch": torch.__version__, "timeout_s": dist_timeout_s(),
                            "layout": a.layout if world > 1 else "row-sharded (forced, one rank)",
                            "row_shards": row_shards if sharded else 1, "query_groups": world // row_shards if sharded else world,
+                           # which schedule the timed legs ran: "overlapped" (the default), "blocking-fallback"
+                           # (the preflight's verdict, or a second attempt of the rank guard), "blocking" (asked
+                           # for with RANGE_DIST_BLOCKING=1)
+                           "schedule": preflight["schedule"] if preflight else "none (query-sharded: no collective on the data path)",
+                           "preflight": preflight,
+                           "guard": {"guarded": bool(os.environ.get("RANGE_GUARD_FD")),
+                                     "attempt": int(os.environ.get("RANGE_GUARD_ATTEMPT", "1")),
+                                     "previous_failure": os.environ.get("RANGE_GUARD_PREVIOUS_FAILURE") or None},
                            "comm_ms_exposed_per_step": per_step(m["comm_ms"], a.steps)}
         if weak is not None:
             res["weak"] = weak
@@ -641,10 +702,66 @@ def rank_main(a, rank, local, world, backend):
         if world == 1 and a.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
         print(json.dumps(res), flush=True)
+    report_stage("done")
     if dist is not None:
         dist.barrier()
         if backend != "threads":
             dist.destroy_process_group()
+
+
+def sharded_preflight(a, model, eng, dist, dev, rank, world, row_shards, shard_group, synth, torch):
+    """See the call site.  Returns the ``dist.preflight`` record (the same on every rank):
+    {"schedule", "blocking_ms", "overlapped_ms", "bit_identical", "ranks_agree", "queries_per_rank"}."""
+    from range_amd.dist import ShardedRange
+    from tools.rank_guard import report_stage
+    B = max(1, a.queries // world) if a.scaling == "strong" else a.queries
+    B = min(B, 16384)
+    q = synth.make_queries(B * world, seed=7, lat_max=90.0)[rank * B:(rank + 1) * B]
+    x = torch.from_numpy(q).to(dev)
+    fault = os.environ.get("RANGE_BENCH_INJECT", "")      # (tests: tests/test_gpu_tools.py)
+
+    def run(m):
+        out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        m.embed(x, out=out, b_max=B)
+        torch.cuda.synchronize(dev)
+        return out, (time.perf_counter() - t0) * 1e3
+
+    def agree(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    report_stage("preflight")
+    rec = {"queries_per_rank": B, "chunks_overlapped": len(model._chunk_bounds(B))}
+    asked_blocking = model.blocking          # RANGE_DIST_BLOCKING=1: by hand, or a second attempt of the guard
+    mb = model if asked_blocking else ShardedRange(eng, "RANGE+", a.beta, group=shard_group, n_chunks=a.shard_chunks or None)
+    if not asked_blocking:
+        mb.blocking, mb.pass1_chunked = True, False
+    out_b, rec["blocking_ms"] = run(mb)
+    finite = bool(torch.isfinite(out_b).all())
+    if asked_blocking:
+        second = int(os.environ.get("RANGE_GUARD_ATTEMPT", "1")) > 1
+        rec.update(schedule="blocking-fallback" if second else "blocking", overlapped_ms=None, bit_identical=None,
+                   why=(os.environ.get("RANGE_GUARD_PREVIOUS_FAILURE") if second else "RANGE_DIST_BLOCKING=1"))
+        if not agree(finite):
+            raise SystemExit(f"bench preflight: the blocking schedule produced non-finite rows on some rank: {rec}")
+        return rec
+    report_stage("preflight")                # (a deadline of its own for the overlapped step)
+    if fault == "hang_overlapped" and rank == world - 1:
+        time.sleep(10_000)
+    out_o, rec["overlapped_ms"] = run(model)
+    same = bool(torch.equal(out_b, out_o))
+    if fault == "mismatch_overlapped" and rank == world - 1:
+        same = False
+    rec["bit_identical"] = same
+    rec["ranks_agree"] = agree(same and finite)
+    rec["schedule"] = "overlapped" if rec["ranks_agree"] else "blocking-fallback"
+    if not rec["ranks_agree"]:
+        rec["why"] = "overlapped != blocking on some rank (or non-finite rows): the timed legs run the blocking schedule"
+    return rec
 
 
 def kept_logits_envelope(measure, a, torch, dev, enc, table, bank, N, L, H):

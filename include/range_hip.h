@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RANGE_ABI_VERSION 8
+#define RANGE_ABI_VERSION 9
 
 #define RANGE_KEY_DIM 256   /* satclip_embeddings width, range/range.py:85-86 */
 #define RANGE_VAL_DIM 1024  /* image_embeddings width,   range/range.py:86, 90 */
@@ -148,6 +148,14 @@ int range_check_async_error(range_ctx* ctx);
 /* Test hook: the NEXT persistent launch on this context (one-launch encoder or fused top-k)
  * behaves as if its in-launch wait had expired.  `stream` is unused. */
 int range_debug_raise_async_error(range_ctx* ctx, range_stream_t stream);
+/* The give-up words as DATA, in stream order: *flag_dev (one float64 of device memory) = 1.0 when a
+ * persistent launch enqueued before this call on this context has given up and the host has not yet
+ * looked (range_check_async_error clears the words), else 0.0.  A rank of a row-sharded job sends the
+ * flag with its rows (range_amd/save.py, range_amd/range.py): every rank then learns of a peer's
+ * give-up from the WORD - never from NaN in the data, which a NaN coordinate produces as well
+ * (a NaN / infinite coordinate gives a NaN row, as in the reference; rows are independent) - and all
+ * ranks refuse the batch together.  No reference counterpart. */
+int range_async_error_flag(range_ctx* ctx, double* flag_dev, range_stream_t stream);
 int range_encode(range_ctx* ctx, const double* lonlat_dev, int64_t B, double* ehat64_dev,
                  float* ehat32_dev, float* xq32_dev, range_stream_t stream);
 
@@ -249,6 +257,14 @@ int64_t range_kept_queries(const range_ctx* ctx);
 int range_topk_stream(range_ctx* ctx, const float* ehat32_dev, int64_t B, int32_t k,
                       float* topk_val_dev, int64_t* topk_idx_dev, range_stream_t stream);
 int range_topk_stream_exact_count(range_ctx* ctx, int64_t* count);
+/* model(coords, return_topk=k) (SURVEY.md 8(b) "Call"; the reference only hints at it:
+ * range/range.py:232): the top-k of the B queries the LAST range_forward / range_forward_host call of
+ * this context embedded.  Their float32 e-hat is still in the context's workspace, so the side channel
+ * costs its scan alone (range_topk_stream's kernels on that operand: the same values and indices as
+ * range_topk_stream on range_encode's output, bit for bit) - no second encoder pass, no second call
+ * into the Python layer's encode.  RANGE_ERR_STATE when B is not the last forward's query count. */
+int range_topk_last(range_ctx* ctx, int64_t B, int32_t k, float* topk_val_dev, int64_t* topk_idx_dev,
+                    range_stream_t stream);
 /* Bench harness: the same call enqueued `repeats` (>= 2) times back to back between ONE pair of
  * HIP events on `stream` (a pair around a single ~15 us launch adds ~5 us of dispatch latency to
  * it); *avg_us = time per call (every launch of the call: the scan with its merge tail, or the

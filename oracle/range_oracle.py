@@ -68,7 +68,9 @@ def sh_features(lonlat: np.ndarray, L: int, mode: str = "analytic") -> np.ndarra
         raise ValueError(f"unknown harmonics_calculation {mode!r}")
     phi, theta = sh_angles(lonlat)
     x = np.cos(theta)
-    s = np.sin(theta)
+    # |sin|: the reference forms it as sqrt((1 - x)(1 + x)) (closed_form.py:11) / (1 - x^2)^(m/2) (the
+    # generated file) - identical for theta in [0, pi], and the reference's continuation beyond +-90 deg
+    s = np.abs(np.sin(theta))
     B = phi.shape[0]
     Y = np.empty((B, L * L), dtype=np.float64)
     c_m = math.sqrt(1.0 / (4.0 * math.pi))

@@ -38,6 +38,7 @@ SYMBOLS = (
     "range_host_copy", "range_topk_stream_exact_count", "range_topk_stream_timed",
     "range_set_pv_mode", "range_get_pv_mode", "range_set_keys", "range_debug_raise_async_error",
     "range_scan_stats_at", "range_p1_splits", "range_check_async_error", "range_stream_read_timed",
+    "range_async_error_flag", "range_topk_last",
 )
 PV_MODES = {"exact": 0, "bf16x3": 1}   # range_set_pv_mode
 
@@ -103,6 +104,8 @@ def load_library() -> C.CDLL:
     lib.range_blend.argtypes = [vp, vp, vp, f32, i64, vp, vp]
     lib.range_topk_stream.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.range_topk_stream_exact_count.argtypes = [vp, C.POINTER(i64)]
+    lib.range_topk_last.argtypes = [vp, i64, i32, vp, vp, vp]
+    lib.range_async_error_flag.argtypes = [vp, vp, vp]
     lib.range_topk_stream_timed.argtypes = [vp, vp, i64, i32, vp, vp, i32, C.POINTER(f32), vp]
     lib.range_stream_read_timed.argtypes = [vp, i32, i32, i32, C.POINTER(f32), vp]
     lib.range_coord_features.argtypes = [vp, i32, vp, i64, vp, vp]
@@ -111,7 +114,7 @@ def load_library() -> C.CDLL:
     lib.range_get_pv_mode.restype = i32
     for name in SYMBOLS:
         getattr(lib, name)
-    if lib.range_abi_version() != 8:
+    if lib.range_abi_version() != 9:
         raise RangeNativeError("librange_hip.so ABI version mismatch (rebuild with ./build.sh)")
     # the library must be built from THIS checkout's sources (a stale in-tree .so travels with the
     # snapshot: it is git-ignored, not gpurun-ignored); RANGE_LIB_PATH builds (tuning) are exempt
@@ -257,6 +260,17 @@ class HipEngine:
         host) - the failed call's rows are NaN by then and the re-issued call takes the fall-back."""
         _check(self.lib, self.lib.range_check_async_error(self._h))
 
+    def async_error_flag(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The give-up words as a float64 DEVICE scalar in stream order (range_async_error_flag): 1.0
+        when a persistent launch enqueued so far on this engine has given up (and the host has not
+        looked yet).  ``out``: a one-element float64 view to write into (a slot of a send buffer)."""
+        if out is None:
+            out = self._empty((1,), torch.float64)
+        elif out.dtype != torch.float64 or out.numel() != 1 or out.device != self.device:
+            raise ValueError("out must be one float64 element on the engine's device")
+        _check(self.lib, self.lib.range_async_error_flag(self._h, out.data_ptr(), self._stream()))
+        return out
+
     def debug_fail_next_persistent_launch(self) -> None:
         """Test hook (range_debug_raise_async_error)."""
         _check(self.lib, self.lib.range_debug_raise_async_error(self._h, None))
@@ -378,6 +392,14 @@ class HipEngine:
         ti = self._empty((B, k), torch.int64)
         _check(self.lib, self.lib.range_topk_stream(self._h, e32.data_ptr(), B, k, tv.data_ptr(),
                                                     ti.data_ptr(), self._stream()))
+        return tv, ti
+
+    def topk_last(self, B: int, k: int):
+        """Top-k of the B queries the last ``forward`` / ``forward_host`` of this engine embedded
+        (range_topk_last: their e-hat is still in the workspace - no second encoder pass)."""
+        tv = self._empty((B, k), torch.float32)
+        ti = self._empty((B, k), torch.int64)
+        _check(self.lib, self.lib.range_topk_last(self._h, B, k, tv.data_ptr(), ti.data_ptr(), self._stream()))
         return tv, ti
 
     def topk_stream_timed(self, e32: torch.Tensor, k: int, repeats: int = 20):

@@ -39,15 +39,35 @@ def prepare_bank(locs, image_embeddings, satclip_embeddings) -> PreparedBank:
     keys = np.asarray(satclip_embeddings).astype(np.float32)           # :85
     if keys.ndim != 2 or keys.shape[1] != 256:
         raise ValueError(f"satclip_embeddings must be (N,256), got {keys.shape}")
-    keys = keys / np.linalg.norm(keys, ord=2, axis=1, keepdims=True)   # :89
+    with np.errstate(invalid="ignore", divide="ignore"):
+        keys = keys / np.linalg.norm(keys, ord=2, axis=1, keepdims=True)   # :89
     values = np.asarray(image_embeddings).astype(np.float32)           # :90
     if values.shape != (keys.shape[0], 1024):
         raise ValueError(f"image_embeddings must be (N,1024), got {values.shape}")
     if locs32.shape != (keys.shape[0], 2):
         raise ValueError(f"locs must be (N,2), got {locs32.shape}")
     xyz = lonlat_rad_to_xyz(locs32 * math.pi / 180)                    # :93-95 (float32)
+    _refuse_degenerate_rows(keys, values, xyz)
     return PreparedBank(np.ascontiguousarray(keys), np.ascontiguousarray(values),
                         np.ascontiguousarray(xyz.astype(np.float32)))
+
+
+def _refuse_degenerate_rows(keys, values, xyz) -> None:
+    """A bank row that is not finite after the reference's preparation - a zero-norm
+    ``satclip_embeddings`` row (0/0 at range.py:89), NaN / infinite embeddings or locations - is
+    refused at load time, by row number.  The reference loads such a bank without complaint and then
+    returns NaN for EVERY query of every batch: the row's logit is NaN and one NaN poisons the whole
+    softmax row (range.py:213-215, 231-236), so all 1024 retrieved columns of all queries are NaN.
+    That is never what a user wants from a 100 000-row bank with one bad row; the decision here
+    (round 6; tests/test_host_cpu.py) is to fail where the cause is, with its row index."""
+    for name, a in (("satclip_embeddings (after L2 normalisation: a zero-norm row?)", keys),
+                    ("image_embeddings", values), ("locs", xyz)):
+        ok = np.isfinite(a).all(axis=1)
+        if not ok.all():
+            bad = np.flatnonzero(~ok)
+            raise ValueError(f"bank row {int(bad[0])} ({bad.size} row(s) in all): {name} not finite. The reference would "
+                             "load this bank and return NaN for every query (one NaN logit poisons each softmax row, "
+                             "range/range.py:213-215); drop or repair the row(s)")
 
 
 def load_bank(path: str) -> PreparedBank:

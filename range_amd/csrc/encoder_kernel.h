@@ -282,7 +282,10 @@ __device__ __forceinline__ void encoder_body(const EncArgs& a, int64_t q0, char*
         phi = (a.lonlat[2 * q] + 180.0) * DEG;                    // spherical_harmonics.py:31
         const double theta = (a.lonlat[2 * q + 1] + 90.0) * DEG;  // :32
         cx = cos(theta);
-        sx = sin(theta);
+        // |sin|: the reference forms sin(theta) as sqrt((1 - x)(1 + x)) (closed_form.py:11) / (1 - x^2)^(m/2)
+        // (generated file), never negative - the same thing for theta in [0, pi], and what continues
+        // the basis to a latitude beyond +-90 degrees the way the reference continues it
+        sx = fabs(sin(theta));
     }
 
     f64x4 acc[QT][NTW];

@@ -111,6 +111,7 @@ struct range_ctx {
     float key_norm_max = 1.f;                // largest |key row| (error bound of the prefilter)
     float xyz_norm_max = 1.f;                // largest |location row| (the geo head's logits must be <= 1 too)
     DevBuf<double> ws_ehat64, ws_h1, ws_h1a, ws_h2, ws_e3;
+    int64_t ws_queries = 0;         // queries whose e-hat the workspace holds (range_forward* / range_encode_raw): range_topk_last
     DevBuf<uint32_t> ws_enc_sync;   // encoder_tile_kernel: 4 phase counters, 64 words apart
     // words of host memory the kernels can write (hipHostMallocMapped; async_err.h): set by a persistent
     // kernel whose bounded wait for other workgroups gave up; read - without synchronising - by the
@@ -460,12 +461,15 @@ int check_softmax_args(range_ctx* c, int64_t B, float tau_sem, float tau_geo) {
     if (!(tau_sem > 0.f)) return fail(RANGE_ERR_INVALID, "tau_sem must be > 0");
     // the constant shift m = tau * log2(e) of the softmax statistics needs every logit <= 1:
     // unit keys (range/range.py:85-89).  A bank that skipped that preparation would overflow.
-    if (c->key_norm_max > 1.001f)
-        return fail(RANGE_ERR_INVALID, "bank keys are not L2-normalised (largest row norm %.4f): the softmax of "
+    // (written as !(x <= 1.001): a row holding NaN or infinity makes the largest norm NaN / inf and is
+    // refused too - the reference would return NaN for EVERY query of every batch against such a bank,
+    // range/range.py:213-215: one NaN logit poisons each softmax row)
+    if (!(c->key_norm_max <= 1.001f))
+        return fail(RANGE_ERR_INVALID, "bank keys are not L2-normalised or not finite (largest row norm %.4f): the softmax of "
                     "range_scan_stats / range_attend needs unit keys, as range/range.py:85-89 prepares them "
                     "(range_topk_stream accepts any norm)", (double)c->key_norm_max);
-    if (tau_geo > 0.f && c->xyz_norm_max > 1.001f)
-        return fail(RANGE_ERR_INVALID, "bank locations are not unit vectors (largest row norm %.4f): the geographic "
+    if (tau_geo > 0.f && !(c->xyz_norm_max <= 1.001f))
+        return fail(RANGE_ERR_INVALID, "bank locations are not unit vectors or not finite (largest row norm %.4f): the geographic "
                     "softmax needs them as range/utils/utils.py:11-16 computes them", (double)c->xyz_norm_max);
     return RANGE_OK;
 }
@@ -849,6 +853,28 @@ int range_debug_raise_async_error(range_ctx* c, range_stream_t) {
     return RANGE_OK;
 }
 
+// The give-up words as DATA, in stream order (range_hip.h: range_async_error_flag): a rank of a
+// row-sharded job sends this with its rows, so that every rank learns from the WORD - not from NaN in
+// the data, which a NaN coordinate produces as well - that a peer's persistent launch gave up.
+__global__ void async_flag_kernel(const uint32_t* __restrict__ err, double* __restrict__ flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        flag[0] = (__hip_atomic_load(err + RANGE_ASYNC_WORD_ENCODER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) |
+                   __hip_atomic_load(err + RANGE_ASYNC_WORD_TOPK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) ? 1.0 : 0.0;
+}
+
+int range_async_error_flag(range_ctx* c, double* flag_dev, range_stream_t stream) {
+    if (!c || !flag_dev) return fail(RANGE_ERR_INVALID, "null argument");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RANGE_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if (!c->d_async_err) {            // (no host-mapped words in this context: nothing can have been reported)
+        HIP_TRY(hipMemsetAsync(flag_dev, 0, sizeof(double), (hipStream_t)stream));
+        return RANGE_OK;
+    }
+    hipLaunchKernelGGL(async_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->d_async_err, flag_dev);
+    HIP_TRY(hipGetLastError());
+    return RANGE_OK;
+}
+
 static int encode_impl(range_ctx* c, const double* lonlat, int64_t B, double* ehat64, float* ehat32,
                        float* xq32, double* eraw64, range_stream_t stream) {
     if (!c || !lonlat || !ehat64 || !ehat32 || !xq32) return fail(RANGE_ERR_INVALID, "null argument");
@@ -882,7 +908,10 @@ int range_encode_raw(range_ctx* c, const double* lonlat, int64_t B, double* eraw
         HIP_TRY(c->ws_ehat32.ensure((size_t)B * 256));
         HIP_TRY(c->ws_xq.ensure((size_t)B * 4));
     }
-    return encode_impl(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, eraw64, stream);
+    c->ws_queries = 0;
+    int rc = encode_impl(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, eraw64, stream);
+    if (rc == RANGE_OK) c->ws_queries = B;
+    return rc;
 }
 
 // Training-free coordinate encoders of the reference (range/range.py:262-272): one thread per
@@ -1392,6 +1421,18 @@ int range_topk_stream(range_ctx* c, const float* ehat32, int64_t B, int32_t k, f
     return topk_stream_impl(c, ehat32, B, k, topk_val, topk_idx, 1, nullptr, stream);
 }
 
+// forward(coords, return_topk=k): the top-k of the queries the context's last range_forward /
+// range_forward_host call embedded - their e-hat (float32) is still in the workspace, so the side
+// channel costs its scan only: no second encoder pass.
+int range_topk_last(range_ctx* c, int64_t B, int32_t k, float* topk_val, int64_t* topk_idx,
+                    range_stream_t stream) {
+    if (!c || !topk_val || !topk_idx) return fail(RANGE_ERR_INVALID, "null argument");
+    if (B <= 0 || c->ws_queries != B)
+        return fail(RANGE_ERR_STATE, "range_topk_last(B=%lld): the workspace holds the e-hat of %lld queries (the last "
+                    "range_forward / range_forward_host call of this context)", (long long)B, (long long)c->ws_queries);
+    return topk_stream_impl(c, c->ws_ehat32.p, B, k, topk_val, topk_idx, 1, nullptr, stream);
+}
+
 int range_topk_stream_timed(range_ctx* c, const float* ehat32, int64_t B, int32_t k, float* topk_val,
                             int64_t* topk_idx, int32_t repeats, float* avg_us, range_stream_t stream) {
     if (repeats < 2 || !avg_us) return fail(RANGE_ERR_INVALID, "repeats must be >= 2 and avg_us non-null");
@@ -1769,10 +1810,12 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     if (!c || !lonlat || !out) return fail(RANGE_ERR_INVALID, "null argument");
     if (model != RANGE_MODEL_RANGE && model != RANGE_MODEL_RANGE_PLUS)
         return fail(RANGE_ERR_INVALID, "unknown model %d", model);
+    c->ws_queries = 0;
     if (B > 0 && B <= 32 && c->small_forward) {
         // a handful of queries: one pass over the bank (attend_small.h)
         int rc = encode_to_workspace(c, lonlat, B, stream);
         if (rc) return rc;
+        c->ws_queries = B;
         DeviceGuard g(c->device);
         return forward_small(c, B, model == RANGE_MODEL_RANGE ? 15.0f : 12.0f, model == RANGE_MODEL_RANGE ? 0.0f : 40.0f,
                              beta, out, (hipStream_t)stream);
@@ -1782,6 +1825,7 @@ int range_forward(range_ctx* c, const double* lonlat, int64_t B, int32_t model, 
     SlabMap map{};
     int rc = forward_to_slabs(c, lonlat, B, model, beta, &map, stream);
     if (rc) return rc;
+    c->ws_queries = B;
     DeviceGuard g(c->device);
     const int64_t n = B * 320;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1830,8 +1874,10 @@ int range_forward_host(range_ctx* c, const double* lonlat, int64_t B, int32_t mo
     const float tau_sem = model == RANGE_MODEL_RANGE ? 15.0f : 12.0f;   // range.py:103, 108
     const float tau_geo = model == RANGE_MODEL_RANGE ? 0.0f : 40.0f;    // range.py:109
     const float bt = model == RANGE_MODEL_RANGE ? 1.0f : beta;
+    c->ws_queries = 0;
     int rc = range_encode(c, lonlat, B, c->ws_ehat64.p, c->ws_ehat32.p, c->ws_xq.p, stream);
     if (rc) return rc;
+    c->ws_queries = B;
     if (B <= 32 && c->small_forward) {
         // a handful of queries: one pass over the bank, one small copy
         rc = forward_small(c, B, tau_sem, tau_geo, bt, c->ws_out64.p, s);

@@ -313,13 +313,49 @@ class ShardedRange:
             getters.append(merged)
         return e64, e32_all, xq_all, chunks, getters, eng.kept_queries() == total
 
+    def _topk_start(self, e32_all: torch.Tensor, chunks, k: int):
+        """The top-k side channel of a forward (``forward(..., topk=k)``): this shard's top-k for ALL
+        scanned queries - their e-hat is gathered already, in chunk-major order - and the start of
+        the ONE all-gather of the packed candidates (north star); returns the function that waits for
+        it and merges this rank's OWN queries' W lists (global rows, ties to the lower row)."""
+        W, total = self.world, e32_all.shape[0]
+        B = total // W
+        # (the keys-only scan: it leaves the logits pass 1 kept for pass 2 alone)
+        tv, ti = self.engine.topk_stream(e32_all, k)
+        packed = self._buf("pack:topk", (total, k, 3), torch.float32, tv.device)
+        packed[:, :, 0] = tv
+        packed[:, :, 1:] = ti.view(torch.float32).reshape(total, k, 2)          # int64 bit pattern
+        staged = self._staged(packed)
+        src = packed.cpu() if staged else packed
+        allp = self._buf("gather:topk", (W * total, k, 3), torch.float32, src.device)
+        nb = src.numel() * src.element_size()
+        self._count("topk", nb * (W - 1), nb * (W - 1))
+        work = dist.all_gather_into_tensor(allp, src, group=self.group, async_op=True)
+        if self.blocking:
+            self._blocked("gather", work.wait)
+
+        def merged():
+            if not self.blocking:
+                self._blocked("gather", work.wait)
+            a = allp.to(tv.device).view(W, total, k, 3)
+            # this rank's rows of the chunk-major order: chunk (lo,hi) holds them at W lo + rank (hi - lo)
+            own = torch.cat([a[:, W * lo + self.rank * (hi - lo):W * lo + (self.rank + 1) * (hi - lo)] for lo, hi in chunks], dim=1)
+            vals = own[..., 0].contiguous()
+            idxs = own[..., 1:].contiguous().view(torch.int64).reshape(W, B, k)
+            return self.engine.merge_topk(vals, idxs)
+        return merged
+
     @torch.no_grad()
-    def forward(self, lonlat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, lonlat: torch.Tensor, out: Optional[torch.Tensor] = None, topk: Optional[int] = None):
         """lonlat: this rank's (B,2) float64 queries (same B on every rank).
         Returns this rank's (B,1280) float64 embeddings (device tensor; ``out`` when given: the
-        chunks are finalized straight into its rows)."""
+        chunks are finalized straight into its rows).  ``topk=k``: returns (embeddings, values (B,k)
+        float32, global bank rows (B,k) int64) - the top-k side channel from the same call: the
+        queries are encoded and gathered ONCE, every shard scans the gathered e-hat behind its pass 1,
+        the candidates travel in one all-gather under pass 2."""
         W = self.world
         e64, e32_all, xq_all, chunks, stats_of, kept = self._scan(lonlat)
+        topk_of = self._topk_start(e32_all, chunks, int(topk)) if topk else None
         pending = []
         for ci, (lo, hi) in enumerate(chunks):
             first, n = W * lo, W * (hi - lo)
@@ -342,6 +378,9 @@ class ShardedRange:
                 self.engine.finalize(recv, e64[lo:hi], out=out[lo:hi])
             else:
                 out[lo:hi] = self.engine.finalize(recv, e64[lo:hi].contiguous())
+        if topk_of is not None:
+            tv, ti = topk_of()
+            return out, tv, ti
         return out
 
     __call__ = forward
@@ -388,23 +427,32 @@ class ShardedRange:
 
     @torch.no_grad()
     def embed(self, lonlat: torch.Tensor, chunk: Optional[int] = None,
-              out: Optional[torch.Tensor] = None, b_max: Optional[int] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, b_max: Optional[int] = None, topk: Optional[int] = None):
         """The product entry of the row-sharded path: this rank's (B,2) queries -> its (B,1280)
         float64 embeddings (device tensor), for ANY per-rank B (ragged across ranks, zero on some),
         in outer steps of ``chunk`` queries per rank (default: ``scan_chunk`` scanned queries per
         step).  Collective: every rank of the group must call it.  ``b_max``: the largest per-rank
-        count, when the caller knows it (equal counts: ``b_max=B``) - saves the scalar all-reduce."""
+        count, when the caller knows it (equal counts: ``b_max=B``) - saves the scalar all-reduce.
+        ``topk=k``: returns (embeddings, values (B,k), global rows (B,k)) - see ``forward``."""
         B = lonlat.shape[0]
         if out is None:
             out = torch.empty((B, 1280), dtype=torch.float64, device=lonlat.device)
+        if topk:
+            tv = torch.empty((B, topk), dtype=torch.float32, device=lonlat.device)
+            ti = torch.empty((B, topk), dtype=torch.int64, device=lonlat.device)
         for lo, n_own, q in self._steps(lonlat, chunk, b_max):
+            if topk:
+                res, v, i = self.forward(q, topk=topk)
+                if n_own:
+                    out[lo:lo + n_own], tv[lo:lo + n_own], ti[lo:lo + n_own] = res[:n_own], v[:n_own], i[:n_own]
+                continue
             if n_own == q.shape[0]:
                 self.forward(q, out=out[lo:lo + n_own])      # (no padding: straight into the result)
                 continue
             res = self.forward(q)
             if n_own:
                 out[lo:lo + n_own] = res[:n_own]
-        return out
+        return (out, tv, ti) if topk else out
 
     @torch.no_grad()
     def embed_sweep(self, lonlat: torch.Tensor, betas, chunk: Optional[int] = None,
@@ -532,22 +580,51 @@ def make_layout(row_shards: int, group=None):
     return mine, rank % R, rank // R
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun)."""
-    import os
+#: seconds a collective (and the rendezvous) may take before the process group gives up - torch's
+#: default is 600 s, the whole budget of a benchmark run: a rank that never arrives must cost two
+#: minutes, not the job.  RANGE_DIST_TIMEOUT_S overrides.  Over RCCL the watchdog thread of
+#: ProcessGroupNCCL aborts the communicator and ends the process when a collective exceeds it
+#: (TORCH_NCCL_ASYNC_ERROR_HANDLING's default); over gloo the waiting call raises.  Either way every
+#: rank of a job whose peer hangs exits non-zero within this bound.
+DEFAULT_TIMEOUT_S = 120.0
+
+
+def dist_timeout_s(timeout_s: Optional[float] = None) -> float:
+    if timeout_s is not None:
+        return float(timeout_s)
+    return float(os.environ.get("RANGE_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None,
+                  attempt: Optional[int] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
+
+    ``timeout_s``: the process group's timeout (default ``DEFAULT_TIMEOUT_S`` = 120 s, or
+    RANGE_DIST_TIMEOUT_S).  ``attempt`` (default: RANGE_DIST_ATTEMPT, else none): a job whose rank
+    processes are started a second time against the SAME store (tools/rank_guard.py: fresh children
+    after a failed first contact; under torchrun the store lives in the agent and survives them)
+    rendezvouses under a prefix of its own, so that nothing the first attempt left in the store -
+    rank addresses, RCCL's unique id - is read by the second."""
+    from datetime import timedelta
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    if attempt is None and os.environ.get("RANGE_DIST_ATTEMPT"):
+        attempt = int(os.environ["RANGE_DIST_ATTEMPT"])
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        timeout = timedelta(seconds=dist_timeout_s(timeout_s))
+        kw = dict(rank=rank, world_size=world, timeout=timeout)
+        if attempt is not None and attempt > 1:
+            store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world, timeout=timeout))
+            store.set_timeout(timeout)
+            kw["store"] = dist.PrefixStore(f"range_attempt{attempt}", store)
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
     return rank, local, world

@@ -53,5 +53,6 @@ def load_model(model_name="RANGE+", pretrained_path=None, device="cuda", **kwarg
         model = ShardedLocationEncoder(args, group=kwargs.get("group"))
     else:
         model = LocationEncoder(args)
-    model.eval()
+    model.eval()                                                           # :49
+    model.to(model.engine.device)   # :50 (the mirror parameters of loc_model already live there: a no-op that keeps the call)
     return model

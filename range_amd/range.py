@@ -91,6 +91,74 @@ def make_engine(enc: EncoderParams, bank: Optional[PreparedBank], device, row_of
     return eng
 
 
+class _FrozenLinear(nn.Module):
+    """The parameters of one SirenNet layer (``weight`` (out,in), ``bias`` (out,) float64, frozen), under
+    the reference's names (satclip/location_encoder.py:121-151)."""
+
+    def __init__(self, weight: np.ndarray, bias: np.ndarray, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.as_tensor(np.asarray(weight), dtype=torch.float64, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.as_tensor(np.asarray(bias), dtype=torch.float64, device=device), requires_grad=False)
+
+
+class _SirenParams(nn.Module):
+    def __init__(self, enc: EncoderParams, device):
+        super().__init__()
+        n = enc.num_hidden_layers
+        self.layers = nn.ModuleList([_FrozenLinear(enc.weights[i], enc.biases[i], device) for i in range(n)])
+        self.last_layer = _FrozenLinear(enc.weights[n], enc.biases[n], device)
+
+
+class SatCLIPLocationModel(nn.Module):
+    """``model.loc_model`` of the reference (range/range.py:83-84, 119-121: ``get_satclip(...).double()``
+    = satclip/location_encoder.py:267-275 ``LocationEncoder(posenc, nnet)``): a module whose call maps
+    (B,2) float64 (lon,lat) degrees to the RAW - un-normalised - (B,256) float64 SatCLIP embedding on
+    the device, and whose parameters are the SirenNet's, frozen (range.py:201-203), float64, on the
+    engine's GPU, under the reference's names (``nnet.layers.{i}.weight`` ...: the checkpoint's
+    ``model.location.*`` keys) - so that ``next(model.parameters()).device``, ``requires_grad`` checks,
+    ``state_dict()`` and ``model.to(device)`` behave as on the reference.  The parameters are a
+    read-only MIRROR: the arithmetic runs in the engine (fused HIP kernel A on its own re-packed copy of
+    the same weights); writing to them does not change the model."""
+
+    def __init__(self, engine, enc: EncoderParams, chunk_size: int = 16384):
+        super().__init__()
+        self.nnet = _SirenParams(enc, engine.device)
+        self._engine = [engine]          # (a list: not a sub-module, not part of the state dict)
+        self._chunk = chunk_size
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, coords: torch.Tensor) -> torch.Tensor:
+        eng = self._engine[0]
+        if not torch.is_tensor(coords):
+            coords = torch.as_tensor(np.asarray(coords))
+        if coords.dim() != 2 or coords.shape[1] != 2:
+            raise ValueError(f"coords must be (B,2) (lon,lat) degrees, got {tuple(coords.shape)}")
+        x = coords.to(device=eng.device, dtype=torch.float64).contiguous()
+        if x.shape[0] == 0:
+            return torch.empty((0, 256), dtype=torch.float64, device=x.device)
+        parts = [eng.encode_raw(x[i:i + self._chunk]) for i in range(0, x.shape[0], self._chunk)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+class _CoordLocationModel(nn.Module):
+    """``loc_model`` of the training-free encoders: the reference's ``DummyLocationEncoder`` (identity;
+    'Direct', 'Cartesian_3D': range.py:155, 161) and ``Wrap()`` (:172) - parameter-free modules there
+    too (``next(model.parameters())`` raises StopIteration on both sides)."""
+
+    def __init__(self, engine, mode):
+        super().__init__()
+        self._engine, self._mode = [engine], mode
+
+    @torch.no_grad()
+    def forward(self, x):
+        if self._mode != _native.COORD_WRAP:
+            return x                                                      # DummyLocationEncoder
+        eng = self._engine[0]
+        x = torch.as_tensor(x).to(device=eng.device, dtype=torch.float64).contiguous()
+        return eng.coord_features(x, _native.COORD_WRAP) if x.shape[0] else torch.empty((0, 4), dtype=torch.float64, device=x.device)
+
+
 class LocationEncoder(nn.Module):
     """RANGE / RANGE+ retrieval-augmented location encoder (reference: range/range.py:69)."""
 
@@ -129,6 +197,7 @@ class LocationEncoder(nn.Module):
             self.engine = make_engine(enc, bank, self._device, sh_eval=getattr(args, "sh_eval", None),
                                       sh_source=getattr(args, "sh_source", None),
                                       pv_mode=getattr(args, "pv_mode", None))
+            self.loc_model = SatCLIPLocationModel(self.engine, enc, self.chunk_size)   # :83-84
         elif self.location_model_name == "SatCLIP":                     # range.py:117-122
             print("Using SatCLIP")
             enc = read_checkpoint(args.pretrained_path)
@@ -140,6 +209,7 @@ class LocationEncoder(nn.Module):
             self._device = _device_of(args.device)
             self.engine = make_engine(enc, None, self._device, sh_eval=getattr(args, "sh_eval", None),
                                       sh_source=getattr(args, "sh_source", None))
+            self.loc_model = SatCLIPLocationModel(self.engine, enc, self.chunk_size)   # :119-121
         elif self.location_model_name in _COORD_MODELS:                 # range.py:152-162, 170-173
             mode, banner = _COORD_MODELS[self.location_model_name]
             print(banner)
@@ -148,11 +218,15 @@ class LocationEncoder(nn.Module):
             self._coord_mode = mode
             self._device = _device_of(args.device)
             self.engine = _native.HipEngine(self._device)
+            self.loc_model = _CoordLocationModel(self.engine, mode)
         else:
             # the reference dispatches more encoder families here (GeoCLIP, CSP, SINR, TaxaBind,
             # Theory, sphere2vec; range.py:124-198): third-party pretrained baselines, out of
             # scope for this engine
             raise NotImplementedError(f"{self.location_model_name} not implemented")
+        self.loc_model.eval()                                               # range.py:201-203
+        for params in self.loc_model.parameters():
+            params.requires_grad = False
         self.eval()
 
     def _coords(self, coords) -> torch.Tensor:
@@ -165,11 +239,26 @@ class LocationEncoder(nn.Module):
         return coords.to(device=self.engine.device, dtype=torch.float64).contiguous()
 
     @torch.no_grad()
-    def forward(self, coords, return_device: bool = False):
+    def forward(self, coords, return_device: bool = False, return_topk: Optional[int] = None):
         """coords (B,2) float64 (lon,lat) deg -> (B,1280) float64 ``numpy.ndarray`` on the host
-        (range.py:222/240).  ``return_device=True`` returns the device tensor instead (no D2H)."""
+        (range.py:222/240).  ``return_device=True`` returns the device tensor instead (no D2H).
+
+        ``return_topk=k`` (1..16; SURVEY.md 8(b) "Call" - the reference only hints at it,
+        range.py:232): the call returns ``(embeddings, values (B,k) float32, indices (B,k) int64)``,
+        the k bank rows most similar to each query (cosine, semantic keys; descending, ties to the
+        lower row) as device tensors - ``model.topk(coords, k)``'s result bit for bit, from the SAME
+        call: the queries are encoded once and the scan runs on the e-hat the forward left in the
+        engine's workspace (``range_topk_last``).  A NaN / infinite coordinate gives a NaN row (as in
+        the reference; rows are independent) and an undefined top-k for that row."""
         x = self._coords(coords)
         B = x.shape[0]
+        if return_topk is not None:
+            k = int(return_topk)
+            if self._model_id is None:
+                raise ValueError("return_topk needs a bank (RANGE / RANGE+)")
+            if not 1 <= k <= _native.MAX_TOPK:
+                raise ValueError(f"return_topk must be in 1..{_native.MAX_TOPK}, got {return_topk}")
+            return self._forward_with_topk(x, k, return_device)
         if getattr(self, "_coord_mode", None) is not None:
             # Direct / Wrap return a device tensor, Cartesian_3D a host ndarray (its rad_to_cart
             # runs in numpy, range.py:265-268)
@@ -201,6 +290,28 @@ class LocationEncoder(nn.Module):
             self.engine.forward(x[i:i + self.chunk_size], self._model_id, beta,
                                 out=out[i:i + self.chunk_size])
         return out
+
+    def _forward_with_topk(self, x: torch.Tensor, k: int, return_device: bool):
+        B = x.shape[0]
+        beta = 1.0 if self._model_id == _native.MODEL_RANGE else float(self.args.beta)
+        tv = torch.empty((B, k), dtype=torch.float32, device=x.device)
+        ti = torch.empty((B, k), dtype=torch.int64, device=x.device)
+        if return_device:
+            out = torch.empty((B, _native.OUT_DIM), dtype=torch.float64, device=x.device)
+        else:
+            out = POOL.take(B, _native.OUT_DIM)
+        for i in range(0, B, self.chunk_size):
+            xc = x[i:i + self.chunk_size]
+            n = xc.shape[0]
+            if return_device:
+                self.engine.forward(xc, self._model_id, beta, out=out[i:i + n])
+            else:
+                self.engine.forward_host(xc, self._model_id, beta, out=out[i:i + n])
+            # (behind the forward on the same stream: the host result above is complete, the scan of
+            # this chunk's e-hat runs while the caller - or the next chunk's encoder launch - goes on)
+            v, j = self.engine.topk_last(n, k)
+            tv[i:i + n], ti[i:i + n] = v, j
+        return out, tv, ti
 
     @torch.no_grad()
     def sweep(self, coords, betas, return_device: bool = False):
@@ -321,6 +432,10 @@ class ShardedLocationEncoder(nn.Module):
                                   sh_eval=getattr(args, "sh_eval", None), sh_source=getattr(args, "sh_source", None),
                                   pv_mode=getattr(args, "pv_mode", None))
         self.sharded = ShardedRange(self.engine, self.location_model_name, args.beta, group=self.shard_group)
+        self.loc_model = SatCLIPLocationModel(self.engine, enc)          # range.py:83-84 (replicated on every rank)
+        self.loc_model.eval()                                            # :201-203
+        for params in self.loc_model.parameters():
+            params.requires_grad = False
         self.eval()
 
     def _coords(self, coords) -> torch.Tensor:
@@ -333,36 +448,56 @@ class ShardedLocationEncoder(nn.Module):
     def _own_rows(self, B: int):
         return (B * self.rank) // self.world, (B * (self.rank + 1)) // self.world
 
-    def _gather_rows(self, own: torch.Tensor, B: int) -> torch.Tensor:
+    def _gather_rows(self, own: torch.Tensor, B: int, with_flags: bool = False):
         """Every rank's rows of a full-batch result -> the full result on every rank (one padded
-        all-gather: the row counts differ by at most one)."""
+        all-gather: the row counts differ by at most one).  ``with_flags`` (float64 rows): one more row
+        travels with every rank's share, carrying its engine's give-up flag (range_async_error_flag:
+        written on the device, in stream order behind the rank's kernels); returns (rows, (W,) flags)."""
         import torch.distributed as dist
         W = self.world
         per = (B + W - 1) // W
-        send = torch.zeros((per,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+        extra = 1 if with_flags else 0
+        send = torch.zeros((per + extra,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
         send[:own.shape[0]] = own
+        if with_flags and hasattr(self.engine, "async_error_flag"):
+            self.engine.async_error_flag(out=send[per].view(-1)[0:1])
         staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
         src = send.cpu() if staged else send
-        allr = torch.empty((W * per,) + tuple(own.shape[1:]), dtype=own.dtype, device=src.device)
+        allr = torch.empty((W * (per + extra),) + tuple(own.shape[1:]), dtype=own.dtype, device=src.device)
         dist.all_gather_into_tensor(allr, src, group=self.group)
         parts = []
         for r in range(W):
             n = (B * (r + 1)) // W - (B * r) // W
-            parts.append(allr[r * per:r * per + n])
-        return torch.cat(parts, dim=0)
+            parts.append(allr[r * (per + extra):r * (per + extra) + n])
+        full = torch.cat(parts, dim=0)
+        if not with_flags:
+            return full
+        return full, allr.view(W, per + 1, -1)[:, per, 0].clone()
 
     @torch.no_grad()
-    def forward(self, coords, return_device: bool = False, local: bool = False):
+    def forward(self, coords, return_device: bool = False, local: bool = False, return_topk: Optional[int] = None):
+        """``return_topk=k``: (embeddings, values (B,k) float32, GLOBAL bank rows (B,k) int64), the
+        top-k from the same call (``LocationEncoder.forward``): the queries are encoded and gathered
+        once, the per-shard candidates merge through ONE all-gather (``ShardedRange.forward``)."""
         x = self._coords(coords)
+        k = None
+        if return_topk is not None:
+            k = int(return_topk)
+            if not 1 <= k <= _native.MAX_TOPK:
+                raise ValueError(f"return_topk must be in 1..{_native.MAX_TOPK}, got {return_topk}")
         if local:
-            out = self.sharded.embed(x)
-            return out if return_device else self._to_host(out)
+            res = self.sharded.embed(x, topk=k)
+            if not k:
+                return res if return_device else self._to_host(res)
+            return (res[0] if return_device else self._to_host(res[0])), res[1], res[2]
         B = x.shape[0]
         lo, hi = self._own_rows(B)
-        full = self._gather_rows(self.sharded.embed(x[lo:hi]), B)
-        if return_device:
-            return full.to(self.engine.device)
-        return self._to_host(full)                                       # range.py:240: a host ndarray
+        res = self.sharded.embed(x[lo:hi], topk=k)
+        own, tk = (res[0], res[1:]) if k else (res, ())
+        full, flags = self._gather_rows(own, B, with_flags=True)
+        tk = tuple(self._gather_rows(t, B).to(self.engine.device) for t in tk)
+        emb = full.to(self.engine.device) if return_device else self._to_host(full, flags)   # range.py:240: a host ndarray
+        return (emb, *tk) if k else emb
 
     @torch.no_grad()
     def sweep(self, coords, betas, return_device: bool = False, local: bool = False):
@@ -376,19 +511,25 @@ class ShardedLocationEncoder(nn.Module):
         B = x.shape[0]
         lo, hi = self._own_rows(B)
         own = self.sharded.embed_sweep(x[lo:hi], betas)                  # (nb, b_own, 1280)
-        full = self._gather_rows(own.permute(1, 0, 2).contiguous(), B).permute(1, 0, 2).contiguous()
-        return full.to(self.engine.device) if return_device else self._to_host(full)
+        full, flags = self._gather_rows(own.permute(1, 0, 2).contiguous(), B, with_flags=True)
+        full = full.permute(1, 0, 2).contiguous()
+        return full.to(self.engine.device) if return_device else self._to_host(full, flags)
 
-    def _to_host(self, t: torch.Tensor) -> np.ndarray:
-        """``.cpu()`` synchronises: a persistent launch of this rank that gave up is known now.  The
-        rows of ANOTHER rank that did (NaN, range_hip.h: range_check_async_error) arrive with the
-        gathered result: every rank holds the same rows, so every rank refuses them here - the
-        verdict is the same on all ranks without a collective of its own."""
+    def _to_host(self, t: torch.Tensor, flags: Optional[torch.Tensor] = None) -> np.ndarray:
+        """``.cpu()`` synchronises: a persistent launch of THIS rank that gave up is known now and is
+        reported (range_hip.h: range_check_async_error).  ANOTHER rank's give-up arrives as its FLAG
+        (``_gather_rows``: the rank's error word, written on the device behind its kernels, travels with
+        its rows): every rank holds the same flags, so every rank refuses the result here - together,
+        without a collective of its own.  The verdict comes from the word, never from the data: a NaN
+        or infinite input coordinate gives a NaN row on every path - as in the reference, whose rows
+        are independent - and is handed out like any other row."""
         h = t.cpu().numpy()
+        bad = [] if flags is None else [int(r) for r in np.flatnonzero(flags.cpu().numpy() != 0.0)]
         self.engine.check_async_error()
-        if h.ndim >= 2 and h.shape[-1] == 1280 and h.size and (np.isnan(h[..., 0]).any() or np.isnan(h[..., 1024]).any()):
-            raise RuntimeError("sharded forward: rows of the result are NaN: a rank's persistent launch gave up "
-                               "(that rank reports it on its side and runs separate launches from now on): re-issue the call")
+        if bad:
+            raise RuntimeError(f"sharded forward: a persistent launch of rank(s) {bad} of the group gave up (their rows of this "
+                               "result are NaN; each reports it on its side and runs separate launches from now on): "
+                               "re-issue the call")
         return h
 
     @torch.no_grad()

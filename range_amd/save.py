@@ -143,8 +143,13 @@ class ShardedEmbeddingPipeline:
             if self.rank == 0:
                 gathered = torch.empty((self.world * per, 1280), dtype=torch.float64, device=self.device)
                 pinned = torch.empty((self.world * per, 1280), dtype=torch.float64).pin_memory()
-            cur = self._slots[slot] = (send, gathered, pinned)
-        send, gathered, pinned = cur
+            # the ranks' give-up flags of the batch (range_async_error_flag), on EVERY rank: one float64
+            # per rank, all-gathered beside the rows and copied to pinned memory with them
+            flag = torch.zeros((1,), dtype=torch.float64, device=self.device)
+            flags = torch.zeros((self.world,), dtype=torch.float64, device=self.device)
+            flags_host = torch.zeros((self.world,), dtype=torch.float64).pin_memory()
+            cur = self._slots[slot] = (send, gathered, pinned, flag, flags, flags_host)
+        send, gathered, pinned = cur[:3]
         W = self.world
         return send[:per], (None if gathered is None else gathered[:W * per]), (None if pinned is None else pinned[:W * per])
 
@@ -171,11 +176,17 @@ class ShardedEmbeddingPipeline:
             sharded.embed(x[lo:hi], out=send[:hi - lo], b_max=per)
             nb = per * 1280 * 8
             sharded._count("results", 0 if r == 0 else nb, (W - 1) * nb if r == 0 else 0)
+            flag, flags, flags_host = self._slots[slot][3:]
+            if hasattr(self.model.engine, "async_error_flag"):
+                self.model.engine.async_error_flag(out=flag)        # (behind this batch's kernels, in stream order)
             host = None
             if self.staged:
                 h = send.cpu()
                 parts = [torch.empty_like(h) for _ in range(W)] if r == 0 else None
                 dist.gather(h, parts, dst=self.root_global, group=self.group)
+                fl = torch.zeros((W,), dtype=torch.float64)
+                dist.all_gather_into_tensor(fl, flag.cpu(), group=self.group)
+                flags_host.copy_(fl)
                 host = parts
             else:
                 # (recorded on the stream the engine launches on - torch's current stream of the ENGINE's
@@ -189,8 +200,10 @@ class ShardedEmbeddingPipeline:
                     side.wait_event(done)
                     parts = list(gathered.view(W, per, 1280).unbind(0)) if r == 0 else None
                     dist.gather(send, parts, dst=self.root_global, group=self.group)
+                    dist.all_gather_into_tensor(flags, flag, group=self.group)       # (8 B per rank: every rank learns of every give-up)
                     if r == 0:
                         pinned.copy_(gathered, non_blocking=True)
+                    flags_host.copy_(flags, non_blocking=True)
                     self._copied[slot].record(side)
             inflight.append((slot, n, per, host))
             i += 1
@@ -203,7 +216,18 @@ class ShardedEmbeddingPipeline:
         W = self.world
         if not self.staged:
             self._copied[slot].synchronize()       # (every rank: its send buffer is free again)
-        self.model.engine.check_async_error()
+        # A rank whose persistent launch gave up left NaN rows in what it sent and SAID so: its error
+        # word travelled with the batch as a flag (range_async_error_flag, all-gathered: 8 B per rank).
+        # EVERY rank holds the same flags and refuses the batch here, together - none is left waiting in
+        # the next batch's collective - and the verdict comes from the word, not from the data: a NaN
+        # or infinite input coordinate gives a NaN row too (as in the reference and in the one-GPU
+        # pipeline, whose rows are independent) and passes through like any other row.
+        bad = [int(r) for r in np.flatnonzero(self._slots[slot][5].numpy() != 0.0)]
+        self.model.engine.check_async_error()      # (this rank's own: reported with the library's message)
+        if bad:
+            raise RuntimeError(f"sharded save_embeddings: a persistent launch of rank(s) {bad} of the group gave up during this "
+                               f"batch of {n} rows (range_hip.h: range_check_async_error; their rows are NaN; each reports it "
+                               "on its side and has switched to separate launches) - re-run the batch")
         if self.rank != 0:
             return None
         out = POOL.take(n, 1280)
@@ -211,15 +235,6 @@ class ShardedEmbeddingPipeline:
             lo, hi = (n * r) // W, (n * (r + 1)) // W
             src = host[r][:hi - lo].numpy() if host is not None else self._slots[slot][2][r * per:r * per + hi - lo].numpy()
             out[lo:hi] = src
-        # The check above is this rank's own.  Another rank whose persistent launch gave up raises on
-        # ITS side and leaves NaN rows in what it sent: rank 0 - the only rank that hands rows out or
-        # writes them - refuses the batch instead of passing them on (a NaN row is NaN in every
-        # element: one column of each half is enough to look at)
-        if np.isnan(out[:, 0]).any() or np.isnan(out[:, 1024]).any():
-            bad = np.flatnonzero(np.isnan(out[:, 0]) | np.isnan(out[:, 1024]))
-            raise RuntimeError(f"sharded save_embeddings: {bad.size} of the {n} gathered rows are NaN (first: row {int(bad[0])}): "
-                               "a rank's persistent launch gave up (range_hip.h: range_check_async_error); that rank "
-                               "reports it on its side and has switched to separate launches - re-run the batch")
         return out
 
 

@@ -123,6 +123,11 @@ class OracleShardEngine:
         out.copy_(res)
         return out
 
+    def topk_stream(self, e32, k):
+        s, _ = self._logits(e32, torch.zeros((e32.shape[0], 4)))
+        tv, ti = O.topk64(s, k)
+        return torch.from_numpy(tv.astype(np.float32)), torch.from_numpy(ti + self.row_offset)
+
     def merge_topk(self, vals, idxs):
         W, B, k = vals.shape
         v = vals.permute(1, 0, 2).reshape(B, W * k).numpy()
@@ -197,6 +202,21 @@ def _worker(rank, world, port, N, B, L, H, ret):
         rv, ri = O.topk64(s, 8)
         assert np.array_equal(ti.numpy(), ri)
         np.testing.assert_allclose(tv.numpy(), rv, atol=1e-7)
+        # forward(topk=k): the side channel of the SAME call (one encode, one gather of the operands, ONE
+        # all-gather of candidates) == topk(), and the embeddings are those of the plain forward - chunked
+        # (the own rows sit at W lo + rank (hi - lo) of every chunk) and not, blocking and not
+        for chunks_n, blocking in ((1, False), (3, False), (2, True)):
+            model = ShardedRange(OracleShardEngine(w, L, shard, r0), "RANGE+", 0.5, n_chunks=chunks_n)
+            model.min_chunk = 2
+            if blocking:
+                model.blocking, model.pass1_chunked = True, False
+            plain = model(torch.from_numpy(q)).numpy()
+            model.reset_bytes()
+            out, fv, fi = model.forward(torch.from_numpy(q), topk=8)
+            assert np.array_equal(out.numpy(), plain)
+            assert np.array_equal(fi.numpy(), ti.numpy()) and np.array_equal(fv.numpy(), tv.numpy())
+            assert model.bytes_sent["topk"] == world * B * 8 * 12 * (world - 1)       # the one all-gather
+            assert model.bytes_sent["gather"] == B * 1040 * (world - 1)              # the operands travelled once
         ret[rank] = "ok"
     except Exception as ex:  # noqa: BLE001
         import traceback
@@ -247,6 +267,8 @@ def _ragged_worker(rank, world, port, ret):
             assert sw.shape == (2, B, 1280)
             tv, ti = model.embed_topk(torch.from_numpy(q), 8, chunk=chunk)
             assert tuple(tv.shape) == (B, 8) and tuple(ti.shape) == (B, 8)
+            out2, fv, fi = model.embed(torch.from_numpy(q), chunk=chunk, topk=8)
+            assert np.array_equal(out2.numpy(), out) and np.array_equal(fi.numpy(), ti.numpy()) and np.array_equal(fv.numpy(), tv.numpy())
             if B:
                 for j, b in enumerate((0.0, 1.0)):
                     assert float(np.abs(sw[j] - O.forward(q, w, L, full, "RANGE+", b)).max()) < 1e-5

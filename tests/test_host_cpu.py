@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.range_abi_version() == 8
+    assert lib.range_abi_version() == 9
     assert lib.range_last_error() is not None
     # the ridge-probe header, same library
     from range_amd import _probe_native
@@ -91,6 +91,43 @@ def test_bank_prep_matches_oracle_bitwise(tmp_path):
         prepare_bank(np.zeros((3, 2)), np.zeros((3, 1024)), np.zeros((3, 128)))
     sub = b.rows(10, 20)
     assert sub.n_rows == 10 and np.array_equal(sub.keys, b.keys[10:20])
+
+
+def test_degenerate_bank_rows_are_refused_at_load_where_the_reference_turns_every_query_nan(tmp_path):
+    """Round-6 decision, pinned: a zero-norm key row (0/0 in the reference's own normalisation,
+    range.py:89), or a NaN / infinite embedding or location, makes the REFERENCE return NaN for every
+    query of every batch (shown here on the oracle, which restates range.py:213-240 op for op); the
+    product refuses the bank at load, naming the row.  Query coordinates are a different matter: a NaN
+    / infinite coordinate gives a NaN row and leaves the other rows alone, on both sides
+    (tests/test_gpu_round6.py)."""
+    locs, vals, keys = synth.make_bank(64, 4)
+    keys = keys.copy()
+    keys[17] = 0.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ob = O.prep_bank(locs, vals, keys)
+    assert np.isnan(ob.keys[17]).all() and np.isfinite(np.delete(ob.keys, 17, axis=0)).all()
+    q = synth.make_queries(5, seed=1)
+    e = np.random.default_rng(0).standard_normal((5, 256))
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    for name in ("RANGE", "RANGE+"):
+        ref = O.retrieve(e, q, ob, name, 0.5)
+        assert np.isnan(ref[:, :1024]).all()          # every query, every retrieved column
+    with pytest.raises(ValueError, match=r"bank row 17 .*satclip_embeddings.*NaN for every query"):
+        prepare_bank(locs, vals, keys)
+    np.savez(str(tmp_path / "bad.npz"), locs=locs, image_embeddings=vals, satclip_embeddings=keys)
+    with pytest.raises(ValueError, match="bank row 17"):
+        load_bank(str(tmp_path / "bad.npz"))
+    # non-finite values / locations: the same verdict, by section
+    locs, vals, keys = synth.make_bank(64, 4)
+    v2 = vals.copy()
+    v2[3, 100] = np.inf
+    with pytest.raises(ValueError, match=r"bank row 3 .*image_embeddings"):
+        prepare_bank(locs, v2, keys)
+    l2 = locs.copy()
+    l2[40, 1] = np.nan
+    with pytest.raises(ValueError, match=r"bank row 40 .*locs"):
+        prepare_bank(l2, vals, keys)
+    prepare_bank(locs, vals, keys)                    # (the clean bank loads)
 
 
 def test_library_carries_this_checkouts_source_hash():
