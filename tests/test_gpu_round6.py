@@ -462,7 +462,7 @@ def _sharded_rank(rank, world, port, ck, db, tmp, ret):
 
 def test_sharded_return_topk_flags_and_nan_coordinates_two_ranks(tmp_path):
     import torch.multiprocessing as mp
-    L, H, N = 10, 64, 5001
+    L, H, N = 20, 256, 5001          # (a shape whose small batches take the one-launch - persistent - encoder)
     ck = synth.write_checkpoint(str(tmp_path / "e.ckpt"), L=L, hidden=H, seed=5)
     db = synth.write_bank(str(tmp_path / "db.npz"), N, 77)
     ret = mp.Manager().dict()
