@@ -567,11 +567,13 @@ def rank_main(a, rank, local, world, backend):
             del m2
             e2.close()
     scan = None
+    with_topk = None
     host_contract = None
     opt_in = None
     envelope = None
     if world == 1 and not sharded and not a.no_extras and default_workload:
         scan = scan_roofline(eng, synth, torch, dev, N, bank)
+        with_topk = return_topk_cost(eng, synth, torch, dev, a)
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
         opt_in = opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev)
         envelope = kept_logits_envelope(measure, a, torch, dev, enc, table, bank, N, L, H)
@@ -614,6 +616,9 @@ def rank_main(a, rank, local, world, backend):
             "value": total_q / dt,
             "unit": "geo-embeddings/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            # what a timed leg is (for comparisons across rounds): version 1 = rounds 1-4 (W warm-up steps, K
+            # timed steps); version 2 = round 5 on: PREHEAT_MS of untimed steps in front of the W warm-up steps
+            "protocol": {"version": 2, "preheat_ms": PREHEAT_MS},
             "preheat": {"untimed_steps_before_warmup": m["preheat_steps"], "target_ms": PREHEAT_MS,
                         "why": "the chip needs ~35 ms of continuous work after idling to hold its clock (tools/clock_ramp.py)"},
             "ms_per_step": step_s * 1e3,
@@ -694,6 +699,8 @@ def rank_main(a, rank, local, world, backend):
             res["best_2d_layout"] = {"layout": best, **layouts[best]}
         if scan is not None:
             res["roofline_scan"] = scan
+        if with_topk is not None:
+            res["return_topk"] = with_topk
         if host_contract is not None:
             res["value_host_contract"] = host_contract["value"]
             res["host_contract"] = host_contract
@@ -843,6 +850,29 @@ def opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev):
             "max_abs_vs_exact_kernel": float(np.abs(got - parity_rows["exact"]).max())}
 
 
+def scan_rocprof(n_rows, nq, keys_mode):
+    """The rocprofv3 median of the same call from the committed kernel-trace passes
+    (profiles/scan_summary.json: tools/profile_bench.sh + profiles/scan_summarize.py, stamped with the
+    SHA-256 of the kernel sources measured) - reported only while this checkout's sources hash to that
+    stamp, like ``pmc_traffic``."""
+    path = os.path.join(REPO, "profiles", "scan_summary.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return {"rocprofv3_median_us": None, "rocprofv3_source": "no profiles/scan_summary.json"}
+    sha = csrc_sha256()
+    if d.get("csrc_sha256") != sha:
+        return {"rocprofv3_median_us": None,
+                "rocprofv3_source": f"profiles/scan_summary.json was measured on other kernel sources (csrc sha256 "
+                                    f"{str(d.get('csrc_sha256'))[:12]}, this checkout {sha[:12]}): re-run tools/profile_bench.sh"}
+    for r in d.get("runs", []):
+        if r["bank_rows"] == n_rows and r["queries"] == nq and r["keys"] == keys_mode:
+            return {"rocprofv3_median_us": r["kernel_median_ns"] / 1e3, "rocprofv3_frac": r["frac_of_8TBps_median"],
+                    "rocprofv3_dispatches": r["dispatches"],
+                    "rocprofv3_source": f"profiles/scan_summary.json (rocprofv3 --kernel-trace of tools/scan_bench.py; kernel sources sha256 {sha[:12]} = this checkout)"}
+    return {"rocprofv3_median_us": None, "rocprofv3_source": "no run of this configuration in profiles/scan_summary.json"}
+
+
 def scan_roofline(eng, synth, torch, dev, N, bank):
     """The HBM-bound regime of the path: the keys-only top-k scan (``range_topk_stream``) for a
     handful of queries, END TO END - one call = the stream kernel with the candidate merge as its
@@ -916,7 +946,8 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
                             "frac_of_copy": copy_us / us,
                             "reference_format_TBps": ref_bytes / (us * 1e-6) / 1e12,
                             "product_path": keys_mode == "bf16",
-                            "exact_fallback_queries": e.topk_stream_exact_count()})
+                            "exact_fallback_queries": e.topk_stream_exact_count(),
+                            **scan_rocprof(n_rows, nq, keys_mode)})
             if e is not eng:
                 e.close()
         del keys_dev
@@ -943,18 +974,79 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
     scan_us, rerank_us = eng.profile_read(_native.PROF_TOPK_STREAM)[0] / 20 * 1e3, eng.profile_read(_native.PROF_TOPK_MERGE)[0] / 20 * 1e3
     eng.profile_enable(False)
     flop = 2.0 * 256 * nq * N
+    # pass A visits every tile_stride-th key tile (range_hip.hip: topk_stream_impl - the same integers here)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_blocks = (N + 15) // 16
+    n_qblocks = (nq + 255) // 256
+    n_splits = max(4, min(min(2 * n_cu // n_qblocks, n_blocks // 8), 64))
+    tg_sample = max(1, min(16, int(os.environ.get("RANGE_TG_SAMPLE", "4"))))
+    tile_stride = max(1, min(tg_sample, n_blocks // n_splits // 4))
     out.append({"kernel": "topk_gemm_kernel<0> (sampled group maxima) + threshold + topk_gemm_kernel<1> (candidates) + "
                           "topk_gemm_rerank_kernel (float32 re-rank): range_amd/csrc/topk_gemm.h",
                 "keys": "fp16", "bank_rows": N, "resident": "infinity_cache", "queries": nq,
                 "us_per_call": us, "us_source": "20 calls between one HIP event pair, after 20 untimed ones",
                 "us_scan_kernels": scan_us, "us_rerank": rerank_us,
-                "bound": "mfma fp16", "algorithmic_flop": flop, "executed_flop": flop * 1.25,
+                "bound": "mfma fp16", "algorithmic_flop": flop, "executed_flop": flop * (1.0 + 1.0 / tile_stride),
+                "pass_a_tile_stride": tile_stride, "bank_splits": n_splits,
                 "achieved_tflops": flop / (us * 1e-6) / 1e12, "peak_tflops": 2500.0,
                 "frac": flop / (us * 1e-6) / 1e12 / 2500.0,
                 "queries_per_s": nq / (us * 1e-6), "product_path": True,
-                "round4_streaming_scan_us": 3890.0,
+                # (not measured by this run: BENCH_r04.json's figure for the same batch through the streaming scan)
+                "reference_from_BENCH_r04_streaming_scan_us": 3890.0,
+                # the 16-bit MFMA rate a register-only loop sustains on random operands (profiles/r06/mfma_f16_peak.log,
+                # tools/micro/mfma_f16_peak.hip): what the data sheet's 2.5 PFLOP/s come to on this chip under load
+                "sustained_peak_tflops_random_operands": 1890.0, "sustained_peak_source": "profiles/r06/mfma_f16_peak.log",
                 "exact_fallback_queries": eng.topk_stream_exact_count()})
     return out
+
+
+def return_topk_cost(eng, synth, torch, dev, a):
+    """``model(coords, return_topk=16)``: the step with the top-k side channel in the SAME call (the
+    forward's e-hat serves the scan: range_topk_last) against the plain step, alternating, one HIP event
+    pair per leg; and against the two separate calls it replaces (forward + ``model.topk``: a second
+    encoder pass).  Never ``value``."""
+    from range_amd import _native
+    B = a.queries
+    x = torch.from_numpy(synth.make_queries(B, seed=7, lat_max=90.0)).to(dev)
+    out = torch.empty((B, 1280), dtype=torch.float64, device=dev)
+
+    def plain():
+        eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+
+    def fused():
+        eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+        return eng.topk_last(B, 16)
+
+    def separate():
+        eng.forward(x, _native.MODEL_RANGE_PLUS, a.beta, out=out)
+        _, e32, _ = eng.encode(x)
+        return eng.topk_stream(e32, 16)
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    for _ in range(8):
+        fused()
+    n = max(5, a.steps)
+    t_plain = t_fused = t_sep = 0.0
+    for _ in range(3):
+        t_plain += timed(plain, n) / 3
+        t_fused += timed(fused, n) / 3
+        t_sep += timed(separate, n) / 3
+    fv, fi = fused()
+    sv, si = separate()
+    return {"what": "forward + top-16 of the same 10 000 queries in ONE call (range_topk_last: no second encoder pass)",
+            "ms_per_step_plain": t_plain, "ms_per_step_with_topk": t_fused, "added_ms": t_fused - t_plain,
+            "added_frac_of_step": (t_fused - t_plain) / t_plain,
+            "ms_per_step_two_calls": t_sep, "two_calls_added_ms": t_sep - t_plain,
+            "value_with_topk": B / (t_fused * 1e-3),
+            "bitwise_equal_to_model_topk": bool(torch.equal(fv, sv) and torch.equal(fi, si))}
 
 
 def host_contract_rate(eng, synth, torch, dev, beta, B):

@@ -49,7 +49,8 @@ def main(root):
                      "frac_of_8TBps_mean": round(streamed / statistics.mean(du) / 1e3 / 8.0, 4),
                      "fetch_size_x2_bytes_per_dispatch": round(2 * 1024 * statistics.mean(fs)) if fs else None,
                      "resident": "dram" if n * (512 if keys == "bf16" else 1024) > 256e6 else "infinity_cache"})
-    print(json.dumps({"what": "rocprofv3 --kernel-trace of tools/scan_bench.py per configuration (3 warm-up + 60 timed calls; "
+    print(json.dumps({"csrc_sha256": sys.argv[2] if len(sys.argv) > 2 else None,
+                      "what": "rocprofv3 --kernel-trace of tools/scan_bench.py per configuration (3 warm-up + 60 timed calls; "
                               "each call = ONE launch: the stream kernel with the merge as its tail); FETCH_SIZE from a "
                               "separate --pmc pass of the same command, x2 (gfx950) and in bytes (the counter is in KB)",
                       "runs": rows}, indent=1))

@@ -120,8 +120,17 @@ def load_library() -> C.CDLL:
     # snapshot: it is git-ignored, not gpurun-ignored); RANGE_LIB_PATH builds (tuning) are exempt
     lib.range_source_sha256.restype = C.c_char_p
     if not os.environ.get("RANGE_LIB_PATH"):
-        from ._srchash import source_sha256
-        built, here = lib.range_source_sha256().decode(), source_sha256()
+        from ._srchash import SourcesMissing, source_sha256
+        built = lib.range_source_sha256().decode()
+        try:
+            here = source_sha256()
+        except SourcesMissing as ex:
+            # a deployment that ships the built library without range_amd/csrc and include/: there is
+            # nothing to compare the stamp with - say so once and go on with the library as built
+            import warnings
+            warnings.warn(f"range_amd: kernel sources not found ({ex}); {LIB_PATH} (source stamp {built[:12]}) is used "
+                          "as built, its stamp unchecked", RuntimeWarning, stacklevel=2)
+            here = built
         if built != here:
             raise RangeNativeError(
                 f"{LIB_PATH} was built from other sources (stamp {built[:12]}, this checkout {here[:12]}): "

@@ -1,5 +1,5 @@
 """SHA-256 over the sources of librange_hip.so (range_amd/csrc/*, include/*.h: file names and
-contents, sorted).  build.sh embeds it in the library (``range_source_sha256()``, and as the literal
+contents, sorted; and build.sh, which holds the compiler flags).  build.sh embeds it in the library (``range_source_sha256()``, and as the literal
 ``RANGE_SRC_SHA256=<hex>`` in the file); ``__graft_entry__.build()`` rebuilds when the in-tree
 library's stamp is not this checkout's, ``range_amd._native`` refuses a library built from other
 sources, ``bench.py`` reports counter traffic only for the sources it was measured on.
@@ -11,12 +11,25 @@ _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MARKER = b"RANGE_SRC_SHA256="
 
 
+class SourcesMissing(FileNotFoundError):
+    """The checkout's kernel sources are not there (a deployment that ships the built library only)."""
+
+
 def source_files():
     out = []
     for d in (os.path.join(_REPO, "range_amd", "csrc"), os.path.join(_REPO, "include")):
-        for name in sorted(os.listdir(d)):
+        try:
+            names = sorted(os.listdir(d))
+        except OSError as ex:
+            raise SourcesMissing(f"{d}: {ex.strerror or ex}") from ex
+        for name in names:
             if name.endswith((".h", ".hip", ".cpp")):
                 out.append(os.path.join(d, name))
+    if not out:
+        raise SourcesMissing(f"no kernel sources under {_REPO}/range_amd/csrc")
+    build = os.path.join(_REPO, "build.sh")            # (the compiler flags live there)
+    if os.path.exists(build):
+        out.append(build)
     return out
 
 

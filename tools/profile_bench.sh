@@ -23,19 +23,21 @@ python3 $R/profiles/pmc_summarize.py $O/pmc1 $O/pmc2 $O/pmc3 > $O/pmc_summary.js
 # the traffic figures bench.py reports, stamped with the hash of the kernel sources measured (copy to profiles/attend_pmc.json)
 python3 $R/bench.py --no-extras --cpu-sample 0 2> /dev/null | tail -1 > $O/bench_line_noextras.json
 python3 $R/profiles/make_attend_pmc.py $O/pmc_summary.json $O/bench_line_noextras.json $tag > $O/attend_pmc.json
-# the bench line proper, with the traffic of the passes above (stamped with this checkout's source hash)
-cp $O/attend_pmc.json $R/profiles/attend_pmc.json
-(cd $R && python3 bench.py > $O/bench.log 2> $O/bench.err)
-tail -1 $O/bench.log > $O/bench_line.json
-find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-echo "bench passes done"
 mkdir -p $O/scan
 for n in 100000 1000000; do for q in 16 32 64; do for k in bf16 f32; do
   rocprofv3 --kernel-trace --output-format csv -d $O/scan/ks_${n}_${q}_${k} -o t -- python3 $R/tools/scan_bench.py --n $n --q $q --keys $k > $O/scan/ks_${n}_${q}_${k}.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/scan/pmc_${n}_${q}_${k} -o p -- python3 $R/tools/scan_bench.py --n $n --q $q --keys $k > $O/scan/pmc_${n}_${q}_${k}.log 2>&1
   echo "scan $n $q $k done"
 done; done; done
-python3 $R/profiles/scan_summarize.py $O/scan > $O/scan_summary.json
+# (stamped with the hash of the kernel sources measured; bench.py quotes the medians while the stamp is this checkout's)
+python3 $R/profiles/scan_summarize.py $O/scan $(python3 $R/range_amd/_srchash.py) > $O/scan_summary.json
+cp $O/scan_summary.json $R/profiles/scan_summary.json
+# the bench line proper, with the traffic of the passes above (stamped with this checkout's source hash)
+cp $O/attend_pmc.json $R/profiles/attend_pmc.json
+(cd $R && python3 bench.py > $O/bench.log 2> $O/bench.err)
+tail -1 $O/bench.log > $O/bench_line.json
+find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+echo "bench passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -o lat -- python3 $R/tools/latency.py > $O/latency.log 2>&1
 find $O/lat -name "*kernel_stats.csv" -exec cp {} $O/latency_kernel_stats.csv \;
 python3 $R/tools/latency.py > $O/latency_plain.log 2>&1

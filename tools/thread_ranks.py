@@ -48,16 +48,20 @@ def run_rank_threads(world: int, fn, *args, timeout: float = 900.0) -> dict:
             except Exception:  # noqa: BLE001
                 pass
 
+    import time
     threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
-    try:
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join(timeout)
-        for r, t in enumerate(threads):
-            if t.is_alive():
-                res.setdefault(r, "timeout: the rank thread did not finish")
-    finally:
-        mtpg._uninstall_threaded_pg()
-        torch._C._distributed_c10d._set_thread_isolation_mode(False)
+    for t in threads:
+        t.start()
+    deadline = time.monotonic() + timeout          # ONE deadline for all ranks (not world x timeout)
+    for t in threads:
+        t.join(max(0.0, deadline - time.monotonic()))
+    alive = [r for r, t in enumerate(threads) if t.is_alive()]
+    for r in alive:
+        res.setdefault(r, f"timeout: the rank thread did not finish within {timeout:.0f} s")
+    if alive:
+        # rank threads are still inside collectives of the threaded process group: it is NOT taken away
+        # from under them (they are daemon threads: the caller reports the timeout and ends the process)
+        return res
+    mtpg._uninstall_threaded_pg()
+    torch._C._distributed_c10d._set_thread_isolation_mode(False)
     return res
