@@ -285,6 +285,33 @@ def test_bankfile_roundtrip_and_shards(tmp_path):
         load_bankfile(str(tmp_path / "bad.rbank"), verify=True)
 
 
+def test_a_sharded_rank_touches_only_its_slice_of_the_bank_file(tmp_path):
+    """What the .rbank is for, pinned: a rank of W maps the file and touches 1/W of each
+    section (+ page rounding) - measured as the pages of the mapped file in the process's RSS (RssFile) by
+    tools/load_time.py's probe in a fresh process - where the reference's .npz is read, cast and
+    normalised WHOLE by every rank (profiles/r06/load_time.log: 3.3 s and 1.6 GB per rank at N = 100 000)."""
+    import json
+    import subprocess
+    import sys
+    from range_amd.bankfile import write_bankfile
+    N, W = 20_000, 8
+    locs, vals, keys = synth.make_bank(N, 2024)
+    path = write_bankfile(str(tmp_path / "db.rbank"), prepare_bank(locs, vals, keys))
+    size_mb = os.path.getsize(path) / 2 ** 20          # (MiB, like /proc's RssFile)
+    res = {}
+    for rank, world in ((5, W), (0, 1)):
+        p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "load_time.py"), "--probe", path, str(rank), str(world)],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        res[world] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    r = res[W]
+    assert r["rows_loaded"] == N // W and r["host_s"] < 0.25                 # (an mmap and three slices: no read, no cast)
+    # (+ 6 MiB: the pages of numpy's / python's own shared objects first touched under the measurement: a
+    # constant 3.6-4 MiB at N = 20 000 and at N = 100 000)
+    assert r["rss_file_mb"] <= size_mb / W + 6.0, (r["rss_file_mb"], size_mb / W)
+    assert res[1]["rss_file_mb"] >= 0.9 * size_mb                            # (the whole bank: every page, once)
+
+
 def test_checkpoint_with_uninstalled_helper_classes(tmp_path):
     """A Lightning checkpoint may pickle helper types of packages that are absent here
     (e.g. lightning.fabric.utilities.data.AttributeDict); the reader must still get the
