@@ -304,26 +304,45 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
     // vector work (it sits in the same basic block as the NEXT tile's MFMAs, interleaved with them):
     // pass A one v_max3 pair per group, pass B one compare per group; the append is ONE rare,
     // wave-uniform branch per tile behind them.
-    auto consume = [&](f32x4 (&acc)[TG_GQ], int tile, int par, bool masked) __attribute__((always_inline)) {
+    // `dep`: an accumulator of the tile whose MFMAs were issued AFTER this tile's (its first query group's).  The
+    // maxima below are inline asm: hipcc pads no hazard for them (MFMA D -> VALU read: up to 12 wait states),
+    // so every statement that reads this tile's accumulators names `dep` as an operand too - it cannot be
+    // placed before the 8 MFMAs that produce `dep` have been issued, 128 cycles behind this tile's last MFMA.
+    // fresh = true (the odd last tile, the tail tile: no younger tile): explicit wait states instead.
+    auto consume = [&](f32x4 (&acc)[TG_GQ], f32x4& dep, int tile, int par, bool masked, bool fresh) __attribute__((always_inline)) {
         const uint32_t row0 = (uint32_t)(t0 + tile * stride) * BLK;
+        if (fresh) {
+            static_assert(TG_GQ == 4, "the wait statement names the four accumulators");
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        }
         if (masked) {
 #pragma unroll
             for (int gi = 0; gi < TG_GQ; ++gi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[gi][r] = row0 + prow[r] < n_valid32 ? acc[gi][r] : -INFINITY;
         }
+        // (the maxima as asm v_max3 / v_max: through fmaxf() hipcc first canonicalises every MFMA result - v_max_f32
+        // x, x, x - which made it 8 vector instructions per group where 2 (pass A) or 3 (pass B) do: with 28 instead
+        // of 8 per tile the "one MFMA, two vector instructions" pattern below ran out of MFMA gaps half way through
+        // the tile; tools/micro/tg_loop.hip: pass A 93 -> 86 us, a full pass 361 -> 331.  NaN operands - a NaN query -
+        // are ignored by the instructions as by fmaxf: such a lane never raises a maximum and never has a hit)
         bool hit = false;
+        float m4[TG_GQ];
 #pragma unroll
         for (int gi = 0; gi < TG_GQ; ++gi) {
-            const float m4 = fmaxf(fmaxf(acc[gi][0], acc[gi][1]), fmaxf(acc[gi][2], acc[gi][3]));
-            if (MODE == 0) mx[gi][par] = fmaxf(mx[gi][par], m4);
-            else hit = hit || m4 >= th[gi];
+            float t;
+            asm("v_max3_f32 %0, %2, %3, %4" : "=v"(t), "+v"(dep) : "v"(acc[gi][0]), "v"(acc[gi][1]), "v"(acc[gi][2]));
+            if (MODE == 0) {
+                asm("v_max3_f32 %0, %2, %3, %4" : "=v"(mx[gi][par]), "+v"(dep) : "v"(t), "v"(acc[gi][3]), "v"(mx[gi][par]));
+            } else {
+                asm("v_max_f32_e32 %0, %2, %3" : "=v"(m4[gi]), "+v"(dep) : "v"(t), "v"(acc[gi][3]));
+                hit = hit || m4[gi] >= th[gi];
+            }
         }
         if (MODE == 1 && __builtin_amdgcn_ballot_w64(hit) != 0ull) {
 #pragma unroll
             for (int gi = 0; gi < TG_GQ; ++gi) {
-                const float m4 = fmaxf(fmaxf(acc[gi][0], acc[gi][1]), fmaxf(acc[gi][2], acc[gi][3]));
-                if (__builtin_amdgcn_ballot_w64(m4 >= th[gi]) == 0ull) continue;      // (wave-uniform)
+                if (__builtin_amdgcn_ballot_w64(m4[gi] >= th[gi]) == 0ull) continue;      // (wave-uniform)
 #ifndef RANGE_EXP_TG_NOAPPEND    // (timing experiment: the rare branch entered, nothing appended)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tg_append(acc[gi][r], th[gi], nc[gi], list_off[gi], row0 + prow[r], a.cand);
@@ -348,33 +367,53 @@ __global__ __launch_bounds__(TG_WAVES * 64, 2) void topk_gemm_kernel(TopkGemmArg
     f32x4 accA[TG_GQ], accB[TG_GQ];
     bool have_b = false;
     const int n_phase_main = (b1_main + TG_KT - 1) / TG_KT;
-    for (int p = 0; p < n_phase; ++p) {
-        // phase p has landed when at most the 4 operations of phase p + 1 are outstanding (own share;
-        // the barrier makes it everybody's); every wave is then also done reading phase p - 1, whose
-        // slot phase p + 2 takes
+    // phase p has landed when at most the 4 operations of phase p + 1 are outstanding (own share; the barrier
+    // makes it everybody's); every wave is then also done reading phase p - 1, whose slot phase p + 2 takes
+    auto phase_begin = [&](int p) __attribute__((always_inline)) {
         if (TG_DMA_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         issue(p + 2);
+    };
+    // The phases that hold two main tiles run in ONE basic block each, the first of them peeled (no earlier
+    // tile to consume): with the per-tile conditions inside the loop (is there a second tile? was there an
+    // earlier one?) the compiler kept flags in scalar registers and branched between the tiles, and the vector
+    // work of tile t - 1 could not be placed beside the MFMAs of tile t across those branches.
+    const int n_full = b1_main / TG_KT;
+    int p = 0;
+    if (n_full > 0) {
+        phase_begin(0);
+        const char* slot = smem + lane * 16;
+        mfma_tile(slot, accA);
+        mfma_tile(slot + TSB_TILE_BYTES, accB);
+        consume(accA, accB[0], 0, 0, false, false);
+        interleave();
+        for (p = 1; p < n_full; ++p) {
+            phase_begin(p);
+            slot = smem + (p % TG_SLOTS) * TG_KT * TSB_TILE_BYTES + lane * 16;
+            mfma_tile(slot, accA);
+            consume(accB, accA[0], 2 * p - 1, 1, false, false);
+            interleave();
+            mfma_tile(slot + TSB_TILE_BYTES, accB);
+            consume(accA, accB[0], 2 * p, 0, false, false);
+            interleave();
+        }
+        have_b = true;
+    }
+    // what is left: a phase with ONE main tile (an odd count), and / or a phase that holds only the tail tile
+    for (; p < n_phase; ++p) {
+        phase_begin(p);
         if (p >= n_phase_main) continue;                     // (a last phase that held only the tail tile)
         const char* slot = smem + (p % TG_SLOTS) * TG_KT * TSB_TILE_BYTES + lane * 16;
         mfma_tile(slot, accA);
-        if (have_b) consume(accB, 2 * p - 1, 1, false);
-        interleave();
-        if (2 * p + 1 < b1_main) {
-            mfma_tile(slot + TSB_TILE_BYTES, accB);
-            consume(accA, 2 * p, 0, false);
-            interleave();
-            have_b = true;
-        } else {
-            consume(accA, 2 * p, 0, false);
-            have_b = false;
-        }
+        if (have_b) consume(accB, accA[0], 2 * p - 1, 1, false, false);
+        consume(accA, accA[0], 2 * p, 0, false, true);
+        have_b = false;
     }
-    if (have_b) consume(accB, 2 * n_phase_main - 1, 1, false);
+    if (have_b) consume(accB, accB[0], 2 * n_phase_main - 1, 1, false, true);
     if (tail_partial) {
         const int tile = b1 - 1;
         mfma_tile(kb + ((int64_t)t0 + (int64_t)tile * stride) * TSB_TILE_BYTES + lane * 16, accA);
-        consume(accA, tile, tile & 1, true);
+        consume(accA, accA[0], tile, tile & 1, true, true);
     }
     // the clamped prefetches of the last phases are still in flight into this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
