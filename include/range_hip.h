@@ -295,7 +295,16 @@ int range_merge_topk(range_ctx* ctx, const float* val_parts_dev, const int64_t* 
  * pass 1 it recomputes the logits tile by tile, forms w = beta*p_sem + (1-beta)*p_geo and
  * accumulates w @ values over THIS ctx's rows (float32 MFMA, exact f32 products).
  *   beta : range.py:238 blend; with tau_geo <= 0 (plain RANGE, range.py:222) pass beta = 1
- *   partial_dev : (B,1024) float32.  Partials of different shards simply add. */
+ *   partial_dev : (B,1024) float32.  Partials of different shards simply add.
+ * ROUNDING AND POSITION.  The float32 sum over the bank rows is formed in pieces (bank splits, or - for
+ * banks / shards of up to 50 000 rows, the default there - the segments of a persistent stream-K walk
+ * over (query tile, bank block) units) that are added in a fixed order: a call is deterministic, bit for
+ * bit, under repetition.  With the split scheme a query's pieces do not depend on where the query sits in
+ * the batch; with the stream-K walk the cut points of a query TILE depend on the tile's index, so the
+ * same query at another position of an equal-sized batch - or in a batch of another size - may differ in
+ * the last bits (measured: < 2e-6 absolute on unit-scale values, tests/test_gpu_round6.py; the reference's
+ * own sgemm blocking depends on the batch shape in the same way).  RANGE_P2_STREAMK=0 in the environment
+ * at range_create selects the position-independent split scheme at every bank size. */
 int range_attend(range_ctx* ctx, const float* ehat32_dev, const float* xq32_dev, int64_t B,
                  float tau_sem, float tau_geo, float beta, const float* stats_global_dev,
                  float* partial_dev, range_stream_t stream);
