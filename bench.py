@@ -123,6 +123,41 @@ def encoder_params(L, H):
                             [w["layers.0.bias"], w["layers.1.bias"], w["last_layer.bias"]])
 
 
+def note(msg: str) -> None:
+    """Progress on stderr (stdout carries the one JSON line): the untimed extras of a default run take a few
+    minutes in all - the CPU baseline alone half of that - and a silent process reads as a hung one."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """CPUs this process can actually USE: its affinity mask, capped by the cgroup's CPU quota (a GPU box
+    of this pool shows 100+ logical CPUs and grants 16: a thread per visible CPU would spin its quota
+    away at every OpenMP barrier).  Independent of --gpus and of OMP_NUM_THREADS."""
+    import math
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse:
+                q, p = parse(open(path).read())
+                if q == "max":
+                    break
+                q, p = int(q), int(p)
+            else:
+                q = int(open(path).read())
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q <= 0:
+                    break
+            n = min(n, max(1, math.ceil(q / p)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -174,13 +209,10 @@ def cpu_baseline(weights, L, bank_arrays, n_sample, model, beta):
     # every CPU this process may run on, whatever OMP_NUM_THREADS the launcher exported (torchrun sets 1
     # for N > 1, this file's own launcher cpu_count / N): the baseline does not depend on --gpus
     n_prev = torch.get_num_threads()
-    try:
-        n_all = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n_all = os.cpu_count() or n_prev
-    n_all = int(os.environ.get("RANGE_CPU_BASELINE_THREADS", "0")) or n_all
+    n_all = int(os.environ.get("RANGE_CPU_BASELINE_THREADS", "0")) or usable_cpus()
     torch.set_num_threads(n_all)
-    host = f"host: {cpu_model_name()}, {os.cpu_count()} logical CPUs, {n_all} usable by this process = torch threads"
+    host = (f"host: {cpu_model_name()}, {os.cpu_count()} logical CPUs, {n_all} usable by this process (affinity and "
+            f"cgroup quota) = torch threads")
 
     def leg(faithful):
         run(q[:64], 64, faithful)                                  # warm-up
@@ -471,7 +503,11 @@ def rank_main(a, rank, local, world, backend):
         return {k: v / steps for k, v in comm_ms.items()}
 
     betas = None if a.sweep is None else [float(v) for v in a.sweep.split(",")]
+    if rank == 0:
+        note("timed leg")
     m = measure(a.scaling, a.steps, a.warmup)
+    if rank == 0:
+        note(f"timed leg done: {m['B'] * world * a.steps / m['dt']:,.0f} geo-embeddings/s; parity check and untimed extras follow")
     B, dt = m["B"], m["dt"]
 
     # ---- parity of the timed result (outside the timed region): 64 of rank 0's rows against the
@@ -572,10 +608,15 @@ def rank_main(a, rank, local, world, backend):
     opt_in = None
     envelope = None
     if world == 1 and not sharded and not a.no_extras and default_workload:
+        note("extras: scan roofline")
         scan = scan_roofline(eng, synth, torch, dev, N, bank)
+        note("extras: return_topk cost")
         with_topk = return_topk_cost(eng, synth, torch, dev, a)
+        note("extras: host contract")
         host_contract = host_contract_rate(eng, synth, torch, dev, a.beta, a.queries)
+        note("extras: opt-in bf16x3")
         opt_in = opt_in_bf16x3(eng, measure, parity_rows, a, torch, dev)
+        note("extras: kept-logit envelope (a 10^6-row bank)")
         envelope = kept_logits_envelope(measure, a, torch, dev, enc, table, bank, N, L, H)
 
     if rank == 0:
@@ -707,7 +748,9 @@ def rank_main(a, rank, local, world, backend):
         if opt_in is not None:
             res["opt_in_bf16x3"] = opt_in
         if world == 1 and a.cpu_sample > 0:
+            note(f"cpu_baseline: the oracle on {usable_cpus()} host threads, {a.cpu_sample} queries (two legs)")
             res["cpu_baseline"] = cpu_baseline(weights, L, bank_arrays, a.cpu_sample, "RANGE+", a.beta)
+            note("cpu_baseline done")
         print(json.dumps(res), flush=True)
     report_stage("done")
     if dist is not None:

@@ -7,12 +7,16 @@
 # queries; bf16-key product path and float32 keys): kernel trace + a separate FETCH_SIZE pass; the
 # small-batch forward (tools/latency.py) kernel trace.
 # Everything lands under gpurun_out/prof_<tag>/; copy the summaries into profiles/<tag>/ afterwards.
+# A second argument selects a part (a box call is limited to 20 minutes): a = kernel trace, counters, scan,
+# bench line; b = latency, batch top-k, rank emulations, clock ramp, encoder, load times.  Default: both.
 set -e
 tag=${1:-r03}
+part=${2:-ab}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [[ $part == *a* ]]; then
 # (--no-extras: only the timed workload, so that per-kernel averages are those of the bench geometry)
 B="python3 $R/bench.py --cpu-sample 0 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- $B --steps 10 --warmup 3 > $O/ks.log 2>&1
@@ -38,6 +42,8 @@ cp $O/attend_pmc.json $R/profiles/attend_pmc.json
 tail -1 $O/bench.log > $O/bench_line.json
 find $O/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 echo "bench passes done"
+fi
+if [[ $part == *b* ]]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -o lat -- python3 $R/tools/latency.py > $O/latency.log 2>&1
 find $O/lat -name "*kernel_stats.csv" -exec cp {} $O/latency_kernel_stats.csv \;
 python3 $R/tools/latency.py > $O/latency_plain.log 2>&1
@@ -52,5 +58,9 @@ python3 $R/tools/shard_emulate.py --layouts 8 > $O/shard_emulate_layouts.log 2>&
 python3 $R/tools/clock_ramp.py 10000 12500 300 > $O/clock_ramp.log 2>&1
 python3 $R/tools/clock_ramp.py 10000 12500 100 3 >> $O/clock_ramp.log 2>&1
 python3 $R/tools/encoder_mid.py > $O/encoder_mid.log 2>&1
+# round 6: what the prepared bank file is for (reference-schema float64 npz against .rbank, whole bank / a rank of 8)
+python3 $R/tools/load_time.py --dir /tmp/range_load_time --json $O/load_time.json > $O/load_time.log 2>&1
+rm -rf /tmp/range_load_time
+fi
 cut -c1-300 $O/bench_line.json
 ls $O
