@@ -62,5 +62,5 @@ python3 $R/tools/encoder_mid.py > $O/encoder_mid.log 2>&1
 python3 $R/tools/load_time.py --dir /tmp/range_load_time --json $O/load_time.json > $O/load_time.log 2>&1
 rm -rf /tmp/range_load_time
 fi
-cut -c1-300 $O/bench_line.json
+[ -f $O/bench_line.json ] && cut -c1-300 $O/bench_line.json
 ls $O
