@@ -72,13 +72,18 @@ def _sample_check(out_rows, q_rows, obank, w, betas):
 def _rank(rank, world, port, ck, rbank, tmp, ret, backend="nccl", body=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (the product's timeout - 120 s, RANGE_DIST_TIMEOUT_S - not torch's 600: a rank that never arrives costs
+    # two minutes of the first multi-GPU run of this suite, not ten)
+    from datetime import timedelta
+    from range_amd.dist import dist_timeout_s
+    tmo = timedelta(seconds=dist_timeout_s())
     if backend == "nccl":
         dev = torch.device("cuda", rank)
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     else:       # rehearsal of THIS test's body on a one-GPU box: gloo ranks sharing cuda:0 (see the test below)
         dev = torch.device("cuda", 0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
     try:
         (body or _body)(rank, world, dev, ck, rbank, tmp, backend)
         ret[rank] = "ok"
@@ -158,6 +163,11 @@ def _body(rank, world, dev, ck, rbank, tmp, backend, total_queries=100_000):
         assert isinstance(full, np.ndarray) and full.shape == (1001, 1280) and full.dtype == np.float64
         _sample_check(full[None, :64], qf[:64], obank, w, (0.5,))
         _sample_check(full[None, -64:], qf[-64:], obank, w, (0.5,))
+        # ... with the top-k side channel from the same call (round 6): one encode, one gather of the operands,
+        # ONE all-gather of the shards' candidates - model.topk()'s result bit for bit
+        full2, fv, fi = m(torch.from_numpy(qf), return_topk=16)
+        tv2, ti2 = m.topk(torch.from_numpy(qf), 16)
+        assert np.array_equal(full2, full) and torch.equal(fi, ti2) and torch.equal(fv, tv2)
         # ---- save_embeddings over the sharded model: every rank embeds its rows, rank 0 receives and writes
         from argparse import Namespace
 
