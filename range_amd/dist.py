@@ -327,7 +327,7 @@ class ShardedRange:
         packed[:, :, 1:] = ti.view(torch.float32).reshape(total, k, 2)          # int64 bit pattern
         staged = self._staged(packed)
         src = packed.cpu() if staged else packed
-        allp = self._buf("gather:topk", (W * total, k, 3), torch.float32, src.device)
+        allp = self._buf("gather:fwd_topk", (W * total, k, 3), torch.float32, src.device)
         nb = src.numel() * src.element_size()
         self._count("topk", nb * (W - 1), nb * (W - 1))
         work = dist.all_gather_into_tensor(allp, src, group=self.group, async_op=True)

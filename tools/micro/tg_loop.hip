@@ -24,8 +24,10 @@
 
 using namespace range_hip;
 
-template <int OCC, int PIPE, int NOLDS, int NOBAR, int NOCONSUME, int FASTMAX = 0>
+template <int OCC, int PIPE, int NOLDS, int NOBAR, int NOCONSUME, int FASTMAX = 0, int GQ = TG_GQ>
 __global__ __launch_bounds__(TG_WAVES * 64, OCC) void tg_var(TopkGemmArgs a) {
+    constexpr int TG_GQ = GQ;               // (shadows the library's: query groups of 16 per wave)
+    constexpr int TG_QBLOCK = TG_WAVES * GQ * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,5 +240,21 @@ int main(int argc, char** argv) {
     timeit("FASTMAX + PIPE", tg_var<2, 1, 0, 0, 0, 1>, TG_LDS_BYTES, flop);
     timeit("FASTMAX + NOLDS", tg_var<2, 0, 1, 0, 0, 1>, TG_LDS_BYTES, flop);
     timeit("FASTMAX + NOBAR", tg_var<2, 0, 0, 1, 0, 1>, TG_LDS_BYTES, flop);
+    // 8 query groups per wave (512 queries per workgroup, one workgroup per CU: half the fragment reads, DMA
+    // pieces and barriers per MFMA; 256 registers of query fragments)
+    {
+        const TopkGemmArgs keep = ga;
+        const dim3 keepg = ggrid;
+        ga.n_qblocks = (int32_t)((B + 511) / 512);
+        ga.n_splits = std::max(4, std::min(std::min(p.multiProcessorCount / ga.n_qblocks, n_blocks / 8), 64));
+        ggrid = dim3((unsigned)(ga.n_qblocks * ga.n_splits));
+        printf("GQ=8: grid=%u (qblocks %d x splits %d)\n", ggrid.x, ga.n_qblocks, ga.n_splits);
+        timeit("GQ8 OCC1", tg_var<1, 0, 0, 0, 0, 0, 8>, TG_LDS_BYTES, flop);
+        timeit("GQ8 OCC1 FASTMAX", tg_var<1, 0, 0, 0, 0, 1, 8>, TG_LDS_BYTES, flop);
+        timeit("GQ8 OCC1 FASTMAX PIPE", tg_var<1, 1, 0, 0, 0, 1, 8>, TG_LDS_BYTES, flop);
+        timeit("GQ8 OCC1 FASTMAX NOLDS", tg_var<1, 0, 1, 0, 0, 1, 8>, TG_LDS_BYTES, flop);
+        ga = keep;
+        ggrid = keepg;
+    }
     return 0;
 }
