@@ -334,16 +334,21 @@ def rank_main(a, rank, local, world, backend):
     from tools import synth
     from range_amd.bank import prepare_bank
 
+    def fatal(msg):
+        # (a configuration error: the rank guard does not answer it with another schedule - rank_guard.EX_FATAL)
+        print(msg, file=sys.stderr, flush=True)
+        raise SystemExit(78)
+
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+        fatal(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+        fatal("bench.py needs an MI355X; there is no CPU path")
     # RANGE_DIST_BACKEND=gloo / threads: rehearsal of the N>1 code path on a box with fewer GPUs than
     # ranks (ranks share devices; gloo stages the collectives through the host; the timing means nothing)
     n_dev = torch.cuda.device_count()
     if backend == "nccl" and world > n_dev:
-        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, {n_dev} visible "
-                         "(RANGE_DIST_BACKEND=gloo or =threads rehearses the path on fewer)")
+        fatal(f"--gpus {world} over RCCL needs {world} GPUs, {n_dev} visible "
+              "(RANGE_DIST_BACKEND=gloo or =threads rehearses the path on fewer)")
     dev = torch.device("cuda", local if backend == "nccl" else local % max(1, n_dev))
     torch.cuda.set_device(dev)
     dist = None

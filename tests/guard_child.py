@@ -9,6 +9,7 @@ faults injected by GUARD_TEST_FAULT:
     sleep_past:<s>    rank 1 sleeps <s> seconds before the preflight collective (no guard needed:
                       the process group's timeout must end the job)
     crash_timed       rank 1 raises in the timed stage (behind the preflight: no other attempt)
+    fatal             every rank ends with rank_guard.EX_FATAL before the preflight (no GPU, bad arguments)
 """
 import json
 import os
@@ -27,6 +28,9 @@ def main():
     from range_amd.dist import init_from_env
     rank, _, world = init_from_env("gloo")
     fault = os.environ.get("GUARD_TEST_FAULT", "")
+    if fault == "fatal":
+        from tools.rank_guard import EX_FATAL
+        sys.exit(EX_FATAL)
     blocking = os.environ.get("RANGE_DIST_BLOCKING", "0") == "1"
     report_stage("setup")
     dist.barrier()

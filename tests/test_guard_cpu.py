@@ -90,6 +90,12 @@ def test_failure_behind_the_preflight_is_not_retried():
     assert dt < 120, dt
 
 
+def test_a_configuration_error_is_not_answered_with_another_schedule():
+    rc, out, err, dt = _launch(2, [GUARD, "--", sys.executable, CHILD], {"GUARD_TEST_FAULT": "fatal"})
+    assert rc != 0 and "no schedule cures it" in err and "starting a fresh child" not in err
+    assert dt < 60, dt
+
+
 def test_default_timeout_is_two_minutes_and_env_overridable(monkeypatch):
     from range_amd import dist as rdist
     monkeypatch.delenv("RANGE_DIST_TIMEOUT_S", raising=False)

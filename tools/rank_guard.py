@@ -20,8 +20,9 @@ Rules (every guard of the job applies them on its own; they converge without tal
     it reported the stage ``timed`` sends the guard to the next attempt (its peers are then stuck in,
     or thrown out of, the same collective: their guards see the same within the process group's
     timeout or their own stage deadline, whichever comes first);
-  * a failure at or behind ``timed`` (the preflight had passed), a failed last attempt, or no time
-    left for another attempt ends the guard non-zero: torchrun then ends the other ranks;
+  * a failure at or behind ``timed`` (the preflight had passed), a child that ends with EX_FATAL (78: no
+    GPU, bad arguments - nothing a schedule cures), a failed last attempt, or no time left for another
+    attempt ends the guard non-zero: torchrun then ends the other ranks;
   * SIGTERM / SIGINT (torchrun tearing the job down) kill the child and end the guard; a guard that
     dies without warning takes its child with it (PR_SET_PDEATHSIG).
 
@@ -41,6 +42,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 #: exit code of a child that itself concluded "this schedule does not work here, try the next one"
 EX_RETRY = 75
+#: exit code of a child whose failure no other schedule can cure (no GPU, bad arguments): never retried
+EX_FATAL = 78
 
 #: the stages a child reports, in order (``report_stage``); the guard's deadlines hang on them
 STAGES = ("init", "setup", "preflight", "timed", "done")
@@ -161,8 +164,9 @@ def guard_rank(argv: Sequence[str], attempts: Sequence[Tuple[str, Dict[str, str]
             reason = (killed or f"exit code {rc}") + f" in attempt {i + 1} ({name})"
             passed = STAGES.index(stage) >= STAGES.index("timed") if stage in STAGES else False
             left = total_timeout - (time.monotonic() - t_job)
-            if passed or i + 1 == len(attempts) or left < 60.0:
-                _log(f"{reason}: giving up" + (" (the preflight had passed: no other schedule would have been timed)" if passed else ""))
+            if passed or rc == EX_FATAL or i + 1 == len(attempts) or left < 60.0:
+                _log(f"{reason}: giving up" + (" (the preflight had passed: no other schedule would have been timed)" if passed else
+                                               " (a configuration error: no schedule cures it)" if rc == EX_FATAL else ""))
                 return rc if rc > 0 else 1
             _log(f"{reason}: starting a fresh child for attempt {i + 2} ({attempts[i + 1][0]})")
         return 1
