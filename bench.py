@@ -1027,7 +1027,7 @@ def scan_roofline(eng, synth, torch, dev, N, bank):
     n_blocks = (N + 15) // 16
     n_qblocks = (nq + 255) // 256
     n_splits = max(4, min(min(2 * n_cu // n_qblocks, n_blocks // 8), 64))
-    tg_sample = max(1, min(16, int(os.environ.get("RANGE_TG_SAMPLE", "4"))))
+    tg_sample = max(1, min(16, int(os.environ.get("RANGE_TG_SAMPLE", "5"))))      # (topk_gemm.h: TG_SAMPLE)
     tile_stride = max(1, min(tg_sample, n_blocks // n_splits // 4))
     out.append({"kernel": "topk_gemm_kernel<0> (sampled group maxima) + threshold + topk_gemm_kernel<1> (candidates) + "
                           "topk_gemm_rerank_kernel (float32 re-rank): range_amd/csrc/topk_gemm.h",

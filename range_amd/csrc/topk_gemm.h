@@ -64,7 +64,7 @@ constexpr int TG_DMA_PER_WAVE = 16 / TG_WAVES;      // 1 KB pieces of a phase's 
 constexpr int TG_KT = 2;                     // key tiles per phase
 constexpr int TG_SLOTS = 3;
 constexpr int TG_LDS_BYTES = TG_SLOTS * TG_KT * TSB_TILE_BYTES;   // 48 KB
-constexpr int TG_SAMPLE = 4;                 // pass A looks at every 4th tile
+constexpr int TG_SAMPLE = 5;                 // pass A looks at every 5th tile (round 6, behind the faster passes: 3: 710, 4: 698, 5: 689, 6: 688 us per 10 000-query call)
 constexpr int TG_CAP = 1024;                 // candidates of a query the re-rank takes in (all lists together)
 constexpr int TG_CAP_L = 32;                 // slots per (query, bank split, lane group) list
 constexpr int TG_MAX_GROUPS = 512;            // row groups per query: splits (<= 64) x 2 tile parities x 4 lane groups
