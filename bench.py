@@ -326,9 +326,8 @@ def main():
 
 def rank_main(a, rank, local, world, backend):
     from tools.rank_guard import report_stage
-    report_stage("init")
     import numpy as np
-    import torch
+    import torch          # (the first import of a fresh box takes 1-2 minutes: the guard's "start" stage, 240 s)
 
     from range_amd import _native
     from tools import synth
@@ -366,6 +365,7 @@ def rank_main(a, rank, local, world, backend):
         raise SystemExit(f"unknown --layout {a.layout!r}")
     replicated = world > 1 and row_shards == 1
     sharded = (world > 1 and not replicated) or a.force_sharded
+    report_stage("init")  # (rendezvous + communicator: 180 s)
     if world > 1 or sharded:
         import torch.distributed as dist
         from range_amd.dist import ShardedRange, init_from_env, make_layout, shard_rows

@@ -50,10 +50,10 @@ STAGES = ("init", "setup", "preflight", "timed", "done")
 
 DEFAULT_DEADLINES = {
     # seconds a child may stay IN a stage.  "start" = until its first report (python start-up and
-    # the first ``import torch`` of a fresh box: 1-2 minutes); "init" = process-group rendezvous +
-    # communicator; "setup" = bank / engine construction; "preflight" = the first steps over the
+    # the first ``import torch`` of a fresh box: 1-2 minutes - the child reports "init" only behind its
+    # imports); "init" = process-group rendezvous + communicator; "setup" = bank / engine construction; "preflight" = the first steps over the
     # collectives, blocking then overlapped - the stage a hang is expected in, if anywhere
-    "start": 240.0, "init": 150.0, "setup": 180.0, "preflight": 60.0, "timed": 300.0, "done": 60.0,
+    "start": 240.0, "init": 180.0, "setup": 180.0, "preflight": 60.0, "timed": 300.0, "done": 60.0,
 }
 
 
